@@ -1,0 +1,216 @@
+/*
+ * rt_mi355.h - C ABI of librt_mi355.so, the MI355X (gfx950) trace core.
+ *
+ * The library replaces ONE path of the reference renderer: everything between
+ * "the host has Vec<BoxData>/Vec<TriangleData>, a grid and a CameraUniform" and
+ * "per pixel, which object was hit and how far away" - i.e. what the reference
+ * does with HierarchicalGrid::build + queue.write_buffer + dispatch_workgroups of
+ * raytracer_unified.wgsl (src/renderer.rs:97-156, 822-868;
+ * src/core/ray_tracing_layer.rs:193-238, 446-467).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all structs are the wire structs of rt_types.h
+ *  - every function returns 0 on success or a negative rt_status; the message is
+ *    available from rt_last_error() until the next call on the same context
+ *  - input pointers are read before the call returns (the caller keeps ownership,
+ *    as with bytemuck::cast_slice + create_buffer_init in the reference)
+ *  - pointers documented "host or device" are classified with
+ *    hipPointerGetAttributes; host outputs are filled synchronously, device
+ *    outputs are written asynchronously on the context's stream (rt_sync waits)
+ *  - a context owns one HIP stream and is not re-entrant; rt_trace_* calls do not
+ *    change scene state (the reference's render(&self))
+ *  - there is no CPU fallback: every entry point that computes fails with
+ *    RT_ERR_NO_DEVICE when no gfx950 device is usable
+ */
+#ifndef RT_MI355_H
+#define RT_MI355_H
+
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument */
+    RT_ERR_NO_DEVICE = -2, /* no usable GPU / HIP runtime error at create */
+    RT_ERR_HIP = -3,       /* HIP runtime error during a call */
+    RT_ERR_STATE = -4,     /* scene or grid missing */
+    RT_ERR_LIMIT = -5      /* a size exceeds a documented limit */
+} rt_status;
+
+/* Object id reported on a miss. */
+#define RT_MISS 0xFFFFFFFFu
+
+/* One traced ray's answer. id is the reference's unified object id
+ * (raytracer_unified.wgsl:533-553: box i -> i, triangle k -> num_boxes + k). */
+typedef struct rt_hit {
+    uint32_t id;
+    float t;
+} rt_hit;
+
+/* Compile-time constants of the reference, made run-time so parity runs and tuned
+ * runs use one binary. rt_default_params() fills in the reference's values. */
+typedef struct rt_params {
+    float finest_cell_size;        /* 16.0            src/grid.rs:6 */
+    uint32_t max_objects_per_cell; /* 8192            src/grid.rs:7 */
+    uint32_t max_dda_steps;        /* 200             raytracer_unified.wgsl:520 */
+    uint32_t wgsl_compat;          /* 0: CPU routines (Moller-Trumbore eps 1e-6, reject t < eps,
+                                         zero direction component -> 1/copysign(1e-8))
+                                         src/core/triangle_intersection.rs:38,74; src/math/ray.rs:9-11
+                                      1: shader (eps 1e-5, accept t > eps, sign(0) = 0)
+                                         raytracer_unified.wgsl:3,252,273,162-166 */
+    uint32_t lod_cull;             /* 1               raytracer_unified.wgsl:147-155,453,539 */
+    uint32_t moving_box_count;     /* 3               raytracer_unified.wgsl:446 */
+    float fov;                     /* 0.785398        raytracer_unified.wgsl:4,643 */
+    float light_direction[3];      /* (0.5,-1,0.3)    raytracer_unified.wgsl:5 */
+    float shadow_offset;           /* 0.001           raytracer_unified.wgsl:687 */
+    uint32_t collect_stats;        /* 0; 1 = count cells/candidates (slower kernels) */
+} rt_params;
+
+/* Which pixels of a W x H frame one call traces. The frame is cut into
+ * tile_w x tile_h tiles numbered row-major; the call traces tiles first,
+ * first+stride, first+2*stride, ... and packs them in that order: local tile j
+ * occupies out[j*tile_w*tile_h ...] in tile-local row-major order (pixels of an
+ * edge tile that fall outside the frame are written as misses). A NULL shard means
+ * the whole frame, row-major. */
+typedef struct rt_shard {
+    uint32_t tile_w, tile_h;
+    uint32_t first, stride;
+} rt_shard;
+
+/* Work counters of the most recent stats-enabled trace call. */
+typedef struct rt_stats {
+    uint64_t rays;          /* primary + shadow (or list) rays traced */
+    uint64_t primary_hits;
+    uint64_t shadow_rays;
+    uint64_t shadow_hits;
+    uint64_t cells_visited; /* DDA iterations (cell records read) */
+    uint64_t tri_tests;     /* Moller-Trumbore candidates tested */
+    uint64_t box_tests;     /* slab candidates tested (moving-box pre-pass included) */
+} rt_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+
+/* Fills *p with the reference's constants. */
+void rt_default_params(rt_params* p);
+
+/* Replaces wgpu Instance/Adapter/Device creation (src/renderer.rs:43-53).
+ * params may be NULL (defaults). */
+int rt_create(rt_ctx** out, int device_id, const rt_params* params);
+void rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);
+/* Message of the most recent failed rt_create (no context exists then). */
+const char* rt_create_error(void);
+
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * context's own; NULL restores the context's stream. */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+/* Blocks until everything queued by this context has finished. */
+int rt_sync(rt_ctx* ctx);
+
+/* Host helper mirroring Camera::forward/right/up/to_uniform (src/camera.rs:51-54,76-122) for
+ * callers that hold a yaw/pitch camera rather than a ready CameraUniform. */
+void rt_camera_to_uniform(const float position[3], float yaw, float pitch, float time, float screen_height,
+                          float fov, int show_grid, CameraUniform* out);
+
+/* ---- scene and grid --------------------------------------------------------------- */
+
+/* Replaces the box/triangle create_buffer_init uploads (src/renderer.rs:119-145).
+ * boxes/tris: host pointers, nb/nt may be 0. Invalidates any grid. */
+int rt_set_scene(rt_ctx* ctx, const BoxData* boxes, uint32_t nb, const TriangleData* tris, uint32_t nt);
+
+/* Replaces the "Fine Cells" upload (src/renderer.rs:99,113-117) for a caller that
+ * already ran HierarchicalGrid::to_gpu_buffers (src/grid.rs:301-358): fine_cells is
+ * the dense FineCellData[n_cells] array (host). Converted to a compact cell list. */
+int rt_set_grid_dense(rt_ctx* ctx, const GridMetadata* meta, const FineCellData* fine_cells, size_t n_cells);
+
+/* Same for TriangleGrid::to_gpu_buffers (src/grid_triangles.rs:215-261): 1040-byte cells. */
+int rt_set_grid_dense_tri(rt_ctx* ctx, const GridMetadata* meta, const TriFineCellData* fine_cells, size_t n_cells);
+
+/* Compact form of the same information: cell_start[n_cells+1], indices[cell_start[n_cells]] (host). */
+int rt_set_grid_csr(rt_ctx* ctx, const GridMetadata* meta, const uint32_t* cell_start, const uint32_t* indices);
+
+typedef enum rt_grid_mode {
+    RT_GRID_HIERARCHICAL = 0, /* HierarchicalGrid::build  src/grid.rs:110-216 */
+    RT_GRID_TRIANGLES = 1     /* TriangleGrid::build      src/grid_triangles.rs:29-124 */
+} rt_grid_mode;
+
+/* Replaces HierarchicalGrid::build / TriangleGrid::build with an on-GPU binning pass
+ * over the current scene: same bounds, dimensions, id order and per-cell cap.
+ * cell_size <= 0 and max_per_cell == 0 select the context's params. */
+int rt_build_grid(rt_ctx* ctx, float cell_size, uint32_t max_per_cell, int mode);
+
+/* Metadata and sizes of the current grid. */
+int rt_get_grid(rt_ctx* ctx, GridMetadata* meta, uint32_t* n_cells, uint32_t* n_refs);
+/* Copies the current grid's cell list back to the host: cell_start[n_cells+1], indices[n_refs]. */
+int rt_read_grid_csr(rt_ctx* ctx, uint32_t* cell_start, uint32_t* indices);
+
+/* Overwrites the vertices of triangles [first, first+count) with xyz9[count*9]
+ * (v0,v1,v2 per triangle; host or device). The grid must be rebuilt afterwards
+ * (rt_build_grid); the reference has no counterpart - it re-uploads whole scenes
+ * (src/main.rs:152-168). */
+int rt_update_vertices(rt_ctx* ctx, const float* xyz9, uint32_t first, uint32_t count);
+
+/* ---- tracing ------------------------------------------------------------------------ */
+
+/* Replaces queue.write_buffer(camera) + dispatch_workgroups(ceil(W/8),ceil(H/8),1)
+ * (src/renderer.rs:822-868; src/core/ray_tracing_layer.rs:446-467), geometry part of
+ * raytracer_unified.wgsl:625-653 (ray generation) and :430-588 (trace_ray).
+ * out_primary (host or device, required): closest hit per pixel.
+ * out_shadow (host or device, may be NULL): for every pixel whose primary ray hit,
+ * one any-hit ray from hit_point + n*shadow_offset towards -normalize(light_direction)
+ * (n = geometric normal turned against the primary ray); id/t of the first accepted
+ * occluder in traversal order, or RT_MISS. Pixels without a primary hit get RT_MISS. */
+int rt_trace_primary(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
+                     const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow);
+
+/* Ray-list mode (the reference's CPU benches trace explicit ray lists:
+ * examples/massive_benchmark.rs:90-98). origins/dirs: n*3 floats each (host or device).
+ * camera supplies position/time/lod for the box LOD cull and may be NULL when the
+ * scene has no boxes. any_hit != 0 stops at the first accepted intersection. */
+int rt_trace_rays(rt_ctx* ctx, const CameraUniform* camera, const float* origins, const float* dirs,
+                  uint32_t n, rt_hit* out, int any_hit);
+
+/* Reassembles a frame from shard outputs: gathered holds, rank after rank, each rank's
+ * packed output of rt_trace_primary with shard {tile_w,tile_h,first=rank,stride=n_ranks};
+ * every rank's block is padded to ceil(n_tiles/n_ranks) tiles. image: width*height
+ * row-major. Both device pointers. No reference counterpart (single GPU there). */
+int rt_assemble_tiles(rt_ctx* ctx, const rt_hit* gathered, uint32_t width, uint32_t height,
+                      uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, rt_hit* image);
+
+/* Fills *info for one pixel the way the shader's debug pixel does
+ * (raytracer_unified.wgsl:695-709), geometry fields only (hit_color is zero). */
+int rt_debug_pixel(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
+                   uint32_t px, uint32_t py, RayDebugInfo* info);
+
+/* Counters of the most recent trace call made with params.collect_stats = 1. */
+int rt_get_stats(rt_ctx* ctx, rt_stats* stats);
+int rt_set_collect_stats(rt_ctx* ctx, int enabled);
+
+/* ---- primitive routines, all pairs ---------------------------------------------------- */
+
+/* GPU counterparts of math::intersect_aabb (src/math/ray.rs:3-36) and
+ * moller_trumbore_intersect (src/core/triangle_intersection.rs:31-82) evaluated for
+ * every (ray, primitive) pair, the shape of the criterion loops
+ * (benches/bounding_volumes.rs:162-175). All pointers host.
+ * out_t[r*n_prims + p]: slab result (-1 on miss) / triangle t (-1 on miss). */
+int rt_intersect_aabb_pairs(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n_rays,
+                            const float* box_min, const float* box_max, uint32_t n_prims, float* out_t);
+int rt_intersect_tri_pairs(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n_rays,
+                           const float* v012, uint32_t n_prims, float* out_t);
+
+/* ---- timing --------------------------------------------------------------------------- */
+
+/* hipEvent pair on the stream the kernels are launched on. */
+int rt_timer_begin(rt_ctx* ctx);
+int rt_timer_end(rt_ctx* ctx, float* elapsed_ms); /* synchronises on the end event */
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_MI355_H */

@@ -1,0 +1,488 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so). TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg - never by
+the ray-tracer_amd package. The wire structs are re-declared here (not imported from the
+product package) so the checker stays independent of the code it checks.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+f32 = np.float32
+u32 = np.uint32
+
+# numpy views of the wire structs (include/rt_types.h)
+TRIANGLE_DTYPE = np.dtype([("v0", f32, 3), ("material_id", f32), ("v1", f32, 3), ("_pad1", f32), ("v2", f32, 3),
+                           ("_pad2", f32), ("uv0", f32, 2), ("uv1", f32, 2), ("uv2", f32, 2), ("_pad3", f32, 2)])
+BOX_DTYPE = np.dtype([("min", f32, 3), ("is_moving", f32), ("max", f32, 3), ("_pad2", f32), ("color", f32, 3),
+                      ("reflectivity", f32), ("center0", f32, 3), ("_pad4", f32), ("center1", f32, 3), ("_pad5", f32),
+                      ("half_size", f32, 3), ("_pad6", f32)])
+HIT_DTYPE = np.dtype([("id", u32), ("t", f32)])
+assert TRIANGLE_DTYPE.itemsize == 80 and BOX_DTYPE.itemsize == 96 and HIT_DTYPE.itemsize == 8
+MISS = 0xFFFFFFFF
+GRID_HIERARCHICAL, GRID_TRIANGLES = 0, 1
+
+
+class CameraUniform(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("_pad1", C.c_float), ("forward", C.c_float * 3), ("_pad2", C.c_float),
+                ("right", C.c_float * 3), ("_pad3", C.c_float), ("up", C.c_float * 3), ("time", C.c_float),
+                ("lod_factor", C.c_float), ("min_pixel_size", C.c_float), ("show_grid", C.c_float),
+                ("_pad4", C.c_float)]
+
+
+class GridMetadata(C.Structure):
+    _fields_ = [("bounds_min", C.c_float * 3), ("num_levels", C.c_uint32), ("bounds_max", C.c_float * 3),
+                ("finest_cell_size", C.c_float), ("grid_sizes", (C.c_uint32 * 4) * 4)]
+
+    @property
+    def fine_dims(self):
+        return tuple(self.grid_sizes[3][k] for k in range(3))
+
+
+class Params(C.Structure):
+    _fields_ = [("finest_cell_size", C.c_float), ("max_objects_per_cell", C.c_uint32), ("max_dda_steps", C.c_uint32),
+                ("wgsl_compat", C.c_uint32), ("lod_cull", C.c_uint32), ("moving_box_count", C.c_uint32),
+                ("fov", C.c_float), ("light_direction", C.c_float * 3), ("shadow_offset", C.c_float),
+                ("collect_stats", C.c_uint32)]
+
+    @classmethod
+    def default(cls, **kw):
+        p = cls(16.0, 8192, 200, 0, 1, 3, 0.785398, (C.c_float * 3)(0.5, -1.0, 0.3), 0.001, 0)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+
+class Shard(C.Structure):
+    _fields_ = [("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("first", C.c_uint32), ("stride", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("primary_hits", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("shadow_hits", C.c_uint64), ("cells_visited", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("box_tests", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class RayDebugInfo(C.Structure):
+    _fields_ = [("ray_origin", C.c_float * 3), ("hit", C.c_float), ("ray_direction", C.c_float * 3),
+                ("distance", C.c_float), ("hit_position", C.c_float * 3), ("object_id", C.c_float),
+                ("hit_normal", C.c_float * 3), ("num_steps", C.c_float), ("hit_color", C.c_float * 3),
+                ("_pad", C.c_float)]
+
+
+class _Scene(C.Structure):
+    _fields_ = [("boxes", C.c_void_p), ("nb", C.c_uint32), ("tris", C.c_void_p), ("nt", C.c_uint32),
+                ("meta", GridMetadata), ("cell_start", C.c_void_p), ("indices", C.c_void_p), ("n_cells", C.c_uint64)]
+
+
+def build(force=False):
+    """Compile oracle/liboracle.so with the committed Makefile (g++)."""
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+            os.path.getmtime(os.path.join(_HERE, n)) for n in ("oracle.cpp", "oracle.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.orc_intersect_aabb.restype = C.c_float
+        L.orc_intersect_aabb.argtypes = [fp, fp, fp, fp, C.c_int]
+        L.orc_moller_trumbore.restype = C.c_int
+        L.orc_moller_trumbore.argtypes = [fp, fp, fp, fp, fp, C.c_int, fp]
+        L.orc_watertight.restype = C.c_int
+        L.orc_watertight.argtypes = [fp, fp, fp, fp, fp, fp]
+        L.orc_batch_intersect_triangles.restype = C.c_int64
+        L.orc_batch_intersect_triangles.argtypes = [fp, fp, C.c_void_p, C.c_void_p, C.c_size_t, fp]
+        L.orc_world_to_cell.restype = None
+        L.orc_world_to_cell.argtypes = [fp, fp, C.c_float, C.POINTER(C.c_int32)]
+        L.orc_aabb_union.restype = None
+        L.orc_aabb_union.argtypes = [fp] * 6
+        L.orc_aabb_center.restype = None
+        L.orc_aabb_center.argtypes = [fp] * 3
+        L.orc_aabb_surface_area.restype = C.c_float
+        L.orc_aabb_surface_area.argtypes = [fp, fp]
+        L.orc_triangle_bounds.restype = None
+        L.orc_triangle_bounds.argtypes = [C.c_void_p, fp, fp]
+        L.orc_intersect_aabb_pairs.restype = None
+        L.orc_intersect_aabb_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                               C.c_int, C.c_void_p]
+        L.orc_intersect_tri_pairs.restype = None
+        L.orc_intersect_tri_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int,
+                                              C.c_void_p]
+        L.orc_camera_to_uniform.restype = None
+        L.orc_camera_to_uniform.argtypes = [fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                            C.POINTER(CameraUniform)]
+        L.orc_grid_build.restype = C.c_void_p
+        L.orc_grid_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_int]
+        L.orc_grid_free.restype = None
+        L.orc_grid_free.argtypes = [C.c_void_p]
+        L.orc_grid_info.restype = None
+        L.orc_grid_info.argtypes = [C.c_void_p, C.POINTER(GridMetadata), C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_grid_copy_csr.restype = None
+        L.orc_grid_copy_csr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_grid_copy_dense.restype = None
+        L.orc_grid_copy_dense.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_grid_copy_dense_tri.restype = None
+        L.orc_grid_copy_dense_tri.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_grid_coarse_counts.restype = C.c_uint64
+        L.orc_grid_coarse_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_trace_primary.restype = None
+        L.orc_trace_primary.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32,
+                                        C.c_uint32, C.POINTER(Shard), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(Stats), C.c_int]
+        L.orc_primary_rays.restype = None
+        L.orc_primary_rays.argtypes = [C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32, C.c_uint32,
+                                       C.c_void_p, C.c_void_p]
+        L.orc_trace_rays.restype = None
+        L.orc_trace_rays.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform), C.c_void_p,
+                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(Stats), C.c_int]
+        L.orc_trace_rays_bruteforce.restype = None
+        L.orc_trace_rays_bruteforce.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform),
+                                                C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+        L.orc_debug_pixel.restype = None
+        L.orc_debug_pixel.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32,
+                                      C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RayDebugInfo)]
+        L.orc_shard_pixels.restype = C.c_uint64
+        L.orc_shard_pixels.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Shard)]
+        L.orc_bvh_build.restype = C.c_void_p
+        L.orc_bvh_build.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_bvh_free.restype = None
+        L.orc_bvh_free.argtypes = [C.c_void_p]
+        L.orc_bvh_stats.restype = None
+        L.orc_bvh_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4
+        L.orc_bvh_trace.restype = C.c_uint64
+        L.orc_bvh_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+        L.orc_linear_scan.restype = C.c_uint64
+        L.orc_linear_scan.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+        L.orc_generate_test_triangles.restype = None
+        L.orc_generate_test_triangles.argtypes = [C.c_uint64, C.c_void_p]
+        L.orc_generate_test_rays.restype = None
+        L.orc_generate_test_rays.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_random_unit_vector.restype = None
+        L.orc_random_unit_vector.argtypes = [C.c_uint32, fp]
+        L.orc_particle_aabbs.restype = None
+        L.orc_particle_aabbs.argtypes = [C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_pyramid_triangles.restype = None
+        L.orc_pyramid_triangles.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+# ---- primitives -------------------------------------------------------------------------
+
+def intersect_aabb(o, d, bmin, bmax, wgsl_compat=0):
+    return float(lib().orc_intersect_aabb(_f3(o), _f3(d), _f3(bmin), _f3(bmax), wgsl_compat))
+
+
+def moller_trumbore(o, d, v0, v1, v2, wgsl_compat=0):
+    out = (C.c_float * 6)()
+    if not lib().orc_moller_trumbore(_f3(o), _f3(d), _f3(v0), _f3(v1), _f3(v2), wgsl_compat, out):
+        return None
+    return dict(t=out[0], u=out[1], v=out[2], normal=(out[3], out[4], out[5]))
+
+
+def watertight(o, d, v0, v1, v2):
+    out = (C.c_float * 6)()
+    if not lib().orc_watertight(_f3(o), _f3(d), _f3(v0), _f3(v1), _f3(v2), out):
+        return None
+    return dict(t=out[0], u=out[1], v=out[2], normal=(out[3], out[4], out[5]))
+
+
+def batch_intersect_triangles(o, d, tris, indices):
+    tris = _c(tris, TRIANGLE_DTYPE)
+    indices = _c(indices, u32)
+    out = (C.c_float * 6)()
+    idx = lib().orc_batch_intersect_triangles(_f3(o), _f3(d), _ptr(tris), _ptr(indices), len(indices), out)
+    if idx < 0:
+        return None
+    return int(idx), dict(t=out[0], u=out[1], v=out[2], normal=(out[3], out[4], out[5]))
+
+
+def world_to_cell(pos, bounds_min, cell_size):
+    out = (C.c_int32 * 3)()
+    lib().orc_world_to_cell(_f3(pos), _f3(bounds_min), cell_size, out)
+    return tuple(out)
+
+
+def aabb_union(amin, amax, bmin, bmax):
+    omin, omax = (C.c_float * 3)(), (C.c_float * 3)()
+    lib().orc_aabb_union(_f3(amin), _f3(amax), _f3(bmin), _f3(bmax), omin, omax)
+    return tuple(omin), tuple(omax)
+
+
+def aabb_center(amin, amax):
+    out = (C.c_float * 3)()
+    lib().orc_aabb_center(_f3(amin), _f3(amax), out)
+    return tuple(out)
+
+
+def aabb_surface_area(amin, amax):
+    return float(lib().orc_aabb_surface_area(_f3(amin), _f3(amax)))
+
+
+def triangle_bounds(tri):
+    tri = _c(tri, TRIANGLE_DTYPE).reshape(1)
+    omin, omax = (C.c_float * 3)(), (C.c_float * 3)()
+    lib().orc_triangle_bounds(_ptr(tri), omin, omax)
+    return tuple(omin), tuple(omax)
+
+
+def intersect_aabb_pairs(origins, dirs, box_min, box_max, wgsl_compat=0):
+    origins, dirs, box_min, box_max = (_c(a, f32).reshape(-1, 3) for a in (origins, dirs, box_min, box_max))
+    out = np.empty((len(origins), len(box_min)), f32)
+    lib().orc_intersect_aabb_pairs(_ptr(origins), _ptr(dirs), len(origins), _ptr(box_min), _ptr(box_max),
+                                   len(box_min), wgsl_compat, _ptr(out))
+    return out
+
+
+def intersect_tri_pairs(origins, dirs, v012, wgsl_compat=0):
+    origins, dirs = (_c(a, f32).reshape(-1, 3) for a in (origins, dirs))
+    v012 = _c(v012, f32).reshape(-1, 9)
+    out = np.empty((len(origins), len(v012)), f32)
+    lib().orc_intersect_tri_pairs(_ptr(origins), _ptr(dirs), len(origins), _ptr(v012), len(v012), wgsl_compat,
+                                  _ptr(out))
+    return out
+
+
+# ---- camera / generators --------------------------------------------------------------------
+
+def camera_to_uniform(position, yaw, pitch, time=0.0, screen_height=1080.0, fov=0.785398, show_grid=False):
+    out = CameraUniform()
+    lib().orc_camera_to_uniform(_f3(position), yaw, pitch, time, screen_height, fov, int(show_grid), C.byref(out))
+    return out
+
+
+def generate_test_triangles(n):
+    out = np.zeros(n, TRIANGLE_DTYPE)
+    lib().orc_generate_test_triangles(n, _ptr(out))
+    return out
+
+
+def generate_test_rays(n):
+    o, d = np.empty((n, 3), f32), np.empty((n, 3), f32)
+    lib().orc_generate_test_rays(n, _ptr(o), _ptr(d))
+    return o, d
+
+
+def random_unit_vector(seed):
+    out = (C.c_float * 3)()
+    lib().orc_random_unit_vector(seed, out)
+    return np.array(out, f32)
+
+
+def particle_aabbs(count, half=0.5):
+    mn, mx = np.empty((count, 3), f32), np.empty((count, 3), f32)
+    lib().orc_particle_aabbs(count, half, _ptr(mn), _ptr(mx))
+    return mn, mx
+
+
+def pyramid_triangles():
+    out = np.zeros(6, TRIANGLE_DTYPE)
+    lib().orc_pyramid_triangles(_ptr(out))
+    return out
+
+
+def triangles_from_xyz9(xyz9):
+    """(n,9) float32 -> TriangleData records (uv/material zero)."""
+    xyz9 = _c(xyz9, f32).reshape(-1, 9)
+    t = np.zeros(len(xyz9), TRIANGLE_DTYPE)
+    t["v0"], t["v1"], t["v2"] = xyz9[:, 0:3], xyz9[:, 3:6], xyz9[:, 6:9]
+    return t
+
+
+def make_box(bmin, bmax, center0=None, center1=None, half=None):
+    """BoxData::new / new_moving (src/types.rs:55-108) for one box."""
+    b = np.zeros((), BOX_DTYPE)
+    bmin, bmax = np.asarray(bmin, f32), np.asarray(bmax, f32)
+    b["min"], b["max"] = bmin, bmax
+    c = (bmin + bmax) * f32(0.5)
+    b["center0"] = c if center0 is None else np.asarray(center0, f32)
+    b["center1"] = c if center1 is None else np.asarray(center1, f32)
+    b["half_size"] = (bmax - bmin) * f32(0.5) if half is None else np.asarray(half, f32)
+    b["is_moving"] = 0.0 if center0 is None else 1.0
+    return b
+
+
+# ---- grids ------------------------------------------------------------------------------------
+
+class Grid:
+    """HierarchicalGrid::build / TriangleGrid::build restated; holds the compact cell list."""
+
+    def __init__(self, boxes, tris, cell_size=16.0, max_per_cell=None, mode=GRID_HIERARCHICAL):
+        self.boxes = _c(boxes if boxes is not None else np.zeros(0, BOX_DTYPE), BOX_DTYPE)
+        self.tris = _c(tris if tris is not None else np.zeros(0, TRIANGLE_DTYPE), TRIANGLE_DTYPE)
+        if max_per_cell is None:
+            max_per_cell = 8192 if mode == GRID_HIERARCHICAL else 256
+        self.mode, self.cell_size, self.max_per_cell = mode, cell_size, max_per_cell
+        h = lib().orc_grid_build(_ptr(self.boxes), len(self.boxes), _ptr(self.tris), len(self.tris), cell_size,
+                                 max_per_cell, mode)
+        if not h:
+            raise MemoryError("oracle grid too large")
+        try:
+            self.meta = GridMetadata()
+            nc, nr, dr = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            lib().orc_grid_info(h, C.byref(self.meta), C.byref(nc), C.byref(nr), C.byref(dr))
+            self.n_cells, self.n_refs, self.dropped = nc.value, nr.value, dr.value
+            self.cell_start = np.empty(self.n_cells + 1, u32)
+            self.indices = np.empty(self.n_refs, u32)
+            lib().orc_grid_copy_csr(h, _ptr(self.cell_start), _ptr(self.indices))
+            n = lib().orc_grid_coarse_counts(h, None, 0)
+            self.coarse = np.empty(n, np.uint8)
+            lib().orc_grid_coarse_counts(h, _ptr(self.coarse), n)
+            self._dense = None
+            if self.n_cells * (32784 if mode == GRID_HIERARCHICAL else 1040) <= (1 << 28):
+                if mode == GRID_HIERARCHICAL:
+                    self._dense = np.empty(self.n_cells * 32784, np.uint8)
+                    lib().orc_grid_copy_dense(h, _ptr(self._dense))
+                else:
+                    self._dense = np.empty(self.n_cells * 1040, np.uint8)
+                    lib().orc_grid_copy_dense_tri(h, _ptr(self._dense))
+        finally:
+            lib().orc_grid_free(h)
+
+    @property
+    def dense(self):
+        """to_gpu_buffers()'s fine-cell bytes (only materialised for grids under 256 MiB)."""
+        return self._dense
+
+    def cell(self, x, y, z):
+        nx, ny, _ = self.meta.fine_dims
+        c = x + y * nx + z * nx * ny
+        return self.indices[self.cell_start[c]:self.cell_start[c + 1]]
+
+
+class Scene:
+    """What a trace call needs: objects + grid (the oracle's view of the bind group)."""
+
+    def __init__(self, boxes, tris, grid=None, **grid_kw):
+        self.grid = grid if grid is not None else Grid(boxes, tris, **grid_kw)
+        self.boxes, self.tris = self.grid.boxes, self.grid.tris
+        s = _Scene()
+        s.boxes, s.nb = self.boxes.ctypes.data, len(self.boxes)
+        s.tris, s.nt = self.tris.ctypes.data, len(self.tris)
+        s.meta = self.grid.meta
+        s.cell_start, s.indices = self.grid.cell_start.ctypes.data, self.grid.indices.ctypes.data
+        s.n_cells = self.grid.n_cells
+        self._s = s
+
+
+def shard_pixels(width, height, shard=None):
+    return int(lib().orc_shard_pixels(width, height, C.byref(shard) if shard is not None else None))
+
+
+def trace_primary(scene, cam, width, height, params=None, shard=None, shadow=True, want_shadow_rays=False,
+                  n_threads=None):
+    """Returns (primary, shadow|None, stats dict[, shadow_o, shadow_d])."""
+    params = params or Params.default()
+    n_threads = n_threads or os.cpu_count() or 1
+    n = shard_pixels(width, height, shard)
+    prim = np.empty(n, HIT_DTYPE)
+    shad = np.empty(n, HIT_DTYPE) if shadow else None
+    so = np.empty((n, 3), f32) if want_shadow_rays else None
+    sd = np.empty((n, 3), f32) if want_shadow_rays else None
+    st = Stats()
+    lib().orc_trace_primary(C.byref(scene._s), C.byref(params), C.byref(cam), width, height,
+                            C.byref(shard) if shard is not None else None, _ptr(prim), _ptr(shad), _ptr(so), _ptr(sd),
+                            C.byref(st), n_threads)
+    if want_shadow_rays:
+        return prim, shad, st.as_dict(), so, sd
+    return prim, shad, st.as_dict()
+
+
+def primary_rays(cam, width, height, params=None):
+    params = params or Params.default()
+    o, d = np.empty((width * height, 3), f32), np.empty((width * height, 3), f32)
+    lib().orc_primary_rays(C.byref(params), C.byref(cam), width, height, _ptr(o), _ptr(d))
+    return o, d
+
+
+def trace_rays(scene, origins, dirs, params=None, cam=None, any_hit=False, n_threads=None):
+    params = params or Params.default()
+    n_threads = n_threads or os.cpu_count() or 1
+    origins, dirs = _c(origins, f32).reshape(-1, 3), _c(dirs, f32).reshape(-1, 3)
+    out = np.empty(len(origins), HIT_DTYPE)
+    st = Stats()
+    lib().orc_trace_rays(C.byref(scene._s), C.byref(params), C.byref(cam) if cam is not None else None, _ptr(origins),
+                         _ptr(dirs), len(origins), _ptr(out), int(any_hit), C.byref(st), n_threads)
+    return out, st.as_dict()
+
+
+def trace_rays_bruteforce(scene, origins, dirs, params=None, cam=None, n_threads=None):
+    params = params or Params.default()
+    n_threads = n_threads or os.cpu_count() or 1
+    origins, dirs = _c(origins, f32).reshape(-1, 3), _c(dirs, f32).reshape(-1, 3)
+    out = np.empty(len(origins), HIT_DTYPE)
+    lib().orc_trace_rays_bruteforce(C.byref(scene._s), C.byref(params), C.byref(cam) if cam is not None else None,
+                                    _ptr(origins), _ptr(dirs), len(origins), _ptr(out), n_threads)
+    return out
+
+
+def debug_pixel(scene, cam, width, height, px, py, params=None):
+    params = params or Params.default()
+    info = RayDebugInfo()
+    lib().orc_debug_pixel(C.byref(scene._s), C.byref(params), C.byref(cam), width, height, px, py, C.byref(info))
+    return info
+
+
+# ---- reference CPU trace path (BVH) ----------------------------------------------------------
+
+class Bvh:
+    def __init__(self, tris):
+        self.tris = _c(tris, TRIANGLE_DTYPE)
+        self._h = lib().orc_bvh_build(_ptr(self.tris), len(self.tris))
+        if not self._h:
+            raise ValueError("empty BVH")
+
+    def stats(self):
+        v = [C.c_uint64() for _ in range(4)]
+        lib().orc_bvh_stats(self._h, *[C.byref(x) for x in v])
+        return dict(zip(("nodes", "leaves", "max_depth", "prims"), (x.value for x in v)))
+
+    def trace(self, origins, dirs, n_threads=1):
+        origins, dirs = _c(origins, f32).reshape(-1, 3), _c(dirs, f32).reshape(-1, 3)
+        out = np.empty(len(origins), f32)
+        hits = lib().orc_bvh_trace(self._h, _ptr(self.tris), _ptr(origins), _ptr(dirs), len(origins), _ptr(out),
+                                   n_threads)
+        return out, int(hits)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_bvh_free(self._h)
+            self._h = None
+
+
+def linear_scan(tris, origins, dirs, n_threads=1):
+    tris = _c(tris, TRIANGLE_DTYPE)
+    origins, dirs = _c(origins, f32).reshape(-1, 3), _c(dirs, f32).reshape(-1, 3)
+    out = np.empty(len(origins), f32)
+    hits = lib().orc_linear_scan(_ptr(tris), len(tris), _ptr(origins), _ptr(dirs), len(origins), _ptr(out), n_threads)
+    return out, int(hits)

@@ -1,0 +1,123 @@
+"""ctypes view of librt_mi355.so - the declarations of include/rt_mi355.h, one to one.
+
+There is no fallback: if the shared library has not been built (ray-tracer_amd/csrc/Makefile,
+or __graft_entry__.build()) importing this module raises, and every computing entry point of
+the library itself fails with RT_ERR_NO_DEVICE when no gfx950 GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_mi355.so")
+
+f32 = np.float32
+u32 = np.uint32
+
+# numpy views of the wire structs (include/rt_types.h; reference src/types.rs, src/grid.rs)
+TRIANGLE_DTYPE = np.dtype([("v0", f32, 3), ("material_id", f32), ("v1", f32, 3), ("_pad1", f32), ("v2", f32, 3),
+                           ("_pad2", f32), ("uv0", f32, 2), ("uv1", f32, 2), ("uv2", f32, 2), ("_pad3", f32, 2)])
+BOX_DTYPE = np.dtype([("min", f32, 3), ("is_moving", f32), ("max", f32, 3), ("_pad2", f32), ("color", f32, 3),
+                      ("reflectivity", f32), ("center0", f32, 3), ("_pad4", f32), ("center1", f32, 3), ("_pad5", f32),
+                      ("half_size", f32, 3), ("_pad6", f32)])
+HIT_DTYPE = np.dtype([("id", u32), ("t", f32)])
+assert TRIANGLE_DTYPE.itemsize == 80 and BOX_DTYPE.itemsize == 96 and HIT_DTYPE.itemsize == 8
+
+RT_MISS = 0xFFFFFFFF
+RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_STATE, RT_ERR_LIMIT = 0, -1, -2, -3, -4, -5
+RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES = 0, 1
+
+
+class CameraUniform(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("_pad1", C.c_float), ("forward", C.c_float * 3), ("_pad2", C.c_float),
+                ("right", C.c_float * 3), ("_pad3", C.c_float), ("up", C.c_float * 3), ("time", C.c_float),
+                ("lod_factor", C.c_float), ("min_pixel_size", C.c_float), ("show_grid", C.c_float),
+                ("_pad4", C.c_float)]
+
+
+class GridMetadata(C.Structure):
+    _fields_ = [("bounds_min", C.c_float * 3), ("num_levels", C.c_uint32), ("bounds_max", C.c_float * 3),
+                ("finest_cell_size", C.c_float), ("grid_sizes", (C.c_uint32 * 4) * 4)]
+
+    @property
+    def fine_dims(self):
+        return tuple(self.grid_sizes[3][k] for k in range(3))
+
+
+class RtParams(C.Structure):
+    _fields_ = [("finest_cell_size", C.c_float), ("max_objects_per_cell", C.c_uint32), ("max_dda_steps", C.c_uint32),
+                ("wgsl_compat", C.c_uint32), ("lod_cull", C.c_uint32), ("moving_box_count", C.c_uint32),
+                ("fov", C.c_float), ("light_direction", C.c_float * 3), ("shadow_offset", C.c_float),
+                ("collect_stats", C.c_uint32)]
+
+
+class RtShard(C.Structure):
+    _fields_ = [("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("first", C.c_uint32), ("stride", C.c_uint32)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("primary_hits", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("shadow_hits", C.c_uint64), ("cells_visited", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("box_tests", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class RayDebugInfo(C.Structure):
+    _fields_ = [("ray_origin", C.c_float * 3), ("hit", C.c_float), ("ray_direction", C.c_float * 3),
+                ("distance", C.c_float), ("hit_position", C.c_float * 3), ("object_id", C.c_float),
+                ("hit_normal", C.c_float * 3), ("num_steps", C.c_float), ("hit_color", C.c_float * 3),
+                ("_pad", C.c_float)]
+
+
+# name -> (restype, argtypes): exactly the functions include/rt_mi355.h declares
+_VP, _FP, _U32, _I = C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_int
+PROTOTYPES = {
+    "rt_default_params": (None, [C.POINTER(RtParams)]),
+    "rt_create": (_I, [C.POINTER(_VP), _I, C.POINTER(RtParams)]),
+    "rt_destroy": (None, [_VP]),
+    "rt_last_error": (C.c_char_p, [_VP]),
+    "rt_create_error": (C.c_char_p, []),
+    "rt_set_stream": (_I, [_VP, _VP]),
+    "rt_sync": (_I, [_VP]),
+    "rt_camera_to_uniform": (None, [_FP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I,
+                                    C.POINTER(CameraUniform)]),
+    "rt_set_scene": (_I, [_VP, _VP, _U32, _VP, _U32]),
+    "rt_set_grid_dense": (_I, [_VP, C.POINTER(GridMetadata), _VP, C.c_size_t]),
+    "rt_set_grid_dense_tri": (_I, [_VP, C.POINTER(GridMetadata), _VP, C.c_size_t]),
+    "rt_set_grid_csr": (_I, [_VP, C.POINTER(GridMetadata), _VP, _VP]),
+    "rt_build_grid": (_I, [_VP, C.c_float, _U32, _I]),
+    "rt_get_grid": (_I, [_VP, C.POINTER(GridMetadata), C.POINTER(_U32), C.POINTER(_U32)]),
+    "rt_read_grid_csr": (_I, [_VP, _VP, _VP]),
+    "rt_update_vertices": (_I, [_VP, _VP, _U32, _U32]),
+    "rt_trace_primary": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), _VP, _VP]),
+    "rt_trace_rays": (_I, [_VP, C.POINTER(CameraUniform), _VP, _VP, _U32, _VP, _I]),
+    "rt_assemble_tiles": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _VP]),
+    "rt_debug_pixel": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, _U32, _U32, C.POINTER(RayDebugInfo)]),
+    "rt_get_stats": (_I, [_VP, C.POINTER(RtStats)]),
+    "rt_set_collect_stats": (_I, [_VP, _I]),
+    "rt_intersect_aabb_pairs": (_I, [_VP, _VP, _VP, _U32, _VP, _VP, _U32, _VP]),
+    "rt_intersect_tri_pairs": (_I, [_VP, _VP, _VP, _U32, _VP, _U32, _VP]),
+    "rt_timer_begin": (_I, [_VP]),
+    "rt_timer_end": (_I, [_VP, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen librt_mi355.so and bind every prototype. Raises if the library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C ray-tracer_amd/csrc` "
+                "(or __graft_entry__.build()). There is no CPU fallback for the trace core.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError here = header and library disagree
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib

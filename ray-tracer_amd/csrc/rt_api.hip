@@ -1,0 +1,761 @@
+// C ABI of librt_mi355.so (include/rt_mi355.h): context, scene/grid upload, trace launches.
+// Host code here only moves bytes, evaluates the per-frame constants and launches kernels;
+// everything a ray does happens in rt_trace.hpp, grid binning in rt_build.hip.
+#include <cmath>
+#include <vector>
+
+#include "rt_internal.hpp"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ---------------------------------------------------------------- small kernels
+
+__global__ void k_emit_cells(const uint32_t* __restrict__ cell_start, uint32_t n_cells, uint2* __restrict__ cells) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cells) {
+        uint32_t a = cell_start[c], b = cell_start[c + 1];
+        cells[c] = make_uint2(a, b - a);
+    }
+}
+
+// One 48-byte record per reference, in cell order.
+__global__ void k_emit_refs(const uint32_t* __restrict__ indices, uint32_t n_refs, const float* __restrict__ tri_v,
+                            uint32_t nb, uint32_t nt, float4* __restrict__ refs) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_refs) return;
+    uint32_t id = indices[r];
+    float4 q0 = make_float4(0.f, 0.f, 0.f, __uint_as_float(id)), q1 = make_float4(0.f, 0.f, 0.f, 0.f), q2 = q1;
+    if (id >= nb) {
+        uint32_t ti = id - nb;
+        if (ti < nt) {
+            const float* v = tri_v + 9 * (size_t)ti;
+            V3 v0 = ld3(v), e1 = ld3(v + 3) - v0, e2 = ld3(v + 6) - v0;
+            q0 = make_float4(v0.x, v0.y, v0.z, __uint_as_float(id));
+            q1 = make_float4(e1.x, e1.y, e1.z, 0.f);
+            q2 = make_float4(e2.x, e2.y, e2.z, 0.f);
+        } else {
+            q0.w = __uint_as_float(REF_INVALID);
+        }
+    }
+    refs[3 * (size_t)r] = q0;
+    refs[3 * (size_t)r + 1] = q1;
+    refs[3 * (size_t)r + 2] = q2;
+}
+
+// reference: raytracer_unified.wgsl:147-155
+__device__ inline bool lod_culled(V3 cam, V3 center, V3 size, float lod_factor, float min_pixel_size) {
+    float distance = length(cam - center);
+    if (distance > 200.0f) return true;
+    float max_size = fmaxf(fmaxf(size.x, size.y), size.z);
+    float apparent = (max_size / distance) * lod_factor;
+    return apparent < min_pixel_size;
+}
+
+// Per-frame box records: interpolated bounds (raytracer_unified.wgsl:200-206) and both
+// LOD-cull outcomes (grid path :536-539, moving-box pre-pass :449-453).
+__global__ void k_box_frame(const BoxData* __restrict__ boxes, uint32_t nb, float t_lerp, V3 cam, float lod_factor,
+                            float min_pixel_size, uint32_t lod_cull, float4* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const BoxData b = boxes[i];
+    V3 center = mix(ld3(b.center0), ld3(b.center1), t_lerp);
+    V3 half = ld3(b.half_size);
+    V3 lo = center - half, hi = center + half;
+    uint32_t flags = 0;
+    if (lod_cull) {
+        V3 gc = (ld3(b.min) + ld3(b.max)) * 0.5f, gs = ld3(b.max) - ld3(b.min);
+        if (lod_culled(cam, gc, gs, lod_factor, min_pixel_size)) flags |= BOX_CULLED_GRID;
+        if (lod_culled(cam, center, half * 2.0f, lod_factor, min_pixel_size)) flags |= BOX_CULLED_PREPASS;
+    }
+    out[4 * (size_t)i] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(flags));
+    out[4 * (size_t)i + 1] = make_float4(hi.x, hi.y, hi.z, 0.f);
+    out[4 * (size_t)i + 2] = make_float4(center.x, center.y, center.z, 0.f);
+    out[4 * (size_t)i + 3] = make_float4(half.x, half.y, half.z, 0.f);
+}
+
+__global__ void k_tri_unpack(const TriangleData* __restrict__ tris, uint32_t nt, float* __restrict__ tri_v) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nt) return;
+    const TriangleData t = tris[i];
+    float* o = tri_v + 9 * (size_t)i;
+    o[0] = t.v0[0], o[1] = t.v0[1], o[2] = t.v0[2];
+    o[3] = t.v1[0], o[4] = t.v1[1], o[5] = t.v1[2];
+    o[6] = t.v2[0], o[7] = t.v2[1], o[8] = t.v2[2];
+}
+
+template <bool WGSL>
+__global__ void k_aabb_pairs(const float* __restrict__ o, const float* __restrict__ d, uint32_t n_rays,
+                             const float* __restrict__ bmin, const float* __restrict__ bmax, uint32_t n_prims,
+                             float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_rays * n_prims) return;
+    uint32_t r = (uint32_t)(i / n_prims), p = (uint32_t)(i % n_prims);
+    V3 dd = ld3(d + 3 * (size_t)r);
+    V3 inv = v3(safe_inv<WGSL>(dd.x), safe_inv<WGSL>(dd.y), safe_inv<WGSL>(dd.z));
+    out[i] = slab(ld3(o + 3 * (size_t)r), inv, ld3(bmin + 3 * (size_t)p), ld3(bmax + 3 * (size_t)p));
+}
+
+template <bool WGSL>
+__global__ void k_tri_pairs(const float* __restrict__ o, const float* __restrict__ d, uint32_t n_rays,
+                            const float* __restrict__ v012, uint32_t n_prims, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_rays * n_prims) return;
+    uint32_t r = (uint32_t)(i / n_prims), p = (uint32_t)(i % n_prims);
+    const float* v = v012 + 9 * (size_t)p;
+    V3 v0 = ld3(v);
+    out[i] = moller_trumbore<WGSL>(ld3(o + 3 * (size_t)r), ld3(d + 3 * (size_t)r), v0, ld3(v + 3) - v0, ld3(v + 6) - v0);
+}
+
+__global__ void k_assemble(const uint2* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+                           uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks, size_t per_rank,
+                           uint2* __restrict__ image) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    uint32_t tile = (y / tile_h) * tiles_x + (x / tile_w);
+    uint32_t rank = tile % n_ranks, lt = tile / n_ranks;
+    size_t src = (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h + (size_t)(y % tile_h) * tile_w + (x % tile_w);
+    image[(size_t)y * width + x] = gathered[src];
+}
+
+// ---------------------------------------------------------------- host helpers
+
+int use(rt_ctx* c) {
+    if (!c) return RT_ERR_INVALID;
+    c->err.clear();
+    RT_HIP(c, hipSetDevice(c->device));
+    return RT_OK;
+}
+
+DevScene make_scene(const rt_ctx* c) {
+    DevScene s;
+    memset(&s, 0, sizeof(s));
+    s.refs = c->refs.as<float4>();
+    s.cells = c->cells.as<uint2>();
+    s.box_frame = c->box_frame.as<float4>();
+    s.nb = c->grid_nb;
+    s.nt = c->nt;
+    s.n_cells = c->n_cells;
+    s.n_refs = c->n_refs;
+    s.gx = c->meta.grid_sizes[RT_GRID_LEVELS - 1][0];
+    s.gy = c->meta.grid_sizes[RT_GRID_LEVELS - 1][1];
+    s.gz = c->meta.grid_sizes[RT_GRID_LEVELS - 1][2];
+    s.max_per_cell = c->params.max_objects_per_cell;
+    s.max_steps = c->params.max_dda_steps;
+    s.moving_start = s.nb >= c->params.moving_box_count ? s.nb - c->params.moving_box_count : 0u;
+    for (int k = 0; k < 3; ++k) {
+        s.bmin[k] = c->meta.bounds_min[k];
+        s.bmax[k] = c->meta.bounds_max[k];
+    }
+    s.cell_size = c->meta.finest_cell_size;
+    return s;
+}
+
+// Per-frame constants the shader evaluates per pixel; evaluated once here with the host libm.
+DevFrame make_frame(const rt_ctx* c, const CameraUniform* cam, uint32_t w, uint32_t h) {
+    DevFrame f;
+    memset(&f, 0, sizeof(f));
+    if (cam) {
+        for (int k = 0; k < 3; ++k) {
+            f.cam_pos[k] = cam->position[k];
+            f.fwd[k] = cam->forward[k];
+            f.right[k] = cam->right[k];
+            f.up[k] = cam->up[k];
+        }
+    }
+    f.fov_scale = tanf(c->params.fov);                       // raytracer_unified.wgsl:643
+    V3 sd = neg(normalize(ld3(c->params.light_direction)));  // raytracer_unified.wgsl:599-600
+    f.shadow_dir[0] = sd.x, f.shadow_dir[1] = sd.y, f.shadow_dir[2] = sd.z;
+    f.shadow_offset = c->params.shadow_offset;
+    f.width = w;
+    f.height = h;
+    return f;
+}
+
+int update_box_frame(rt_ctx* c, const CameraUniform* cam) {
+    if (c->grid_nb == 0) return RT_OK;
+    if (!cam) return fail(c, RT_ERR_INVALID, "camera is required when the scene has boxes (LOD cull, box motion)");
+    RT_HIP(c, c->box_frame.reserve((size_t)c->nb * 4 * sizeof(float4)));
+    float t_lerp = (sinf(cam->time * 2.0f) + 1.0f) * 0.5f;  // raytracer_unified.wgsl:201,449
+    hipLaunchKernelGGL(k_box_frame, dim3((c->nb + 255) / 256), dim3(256), 0, c->stream, c->boxes.as<BoxData>(), c->nb,
+                       t_lerp, ld3(cam->position), cam->lod_factor, cam->min_pixel_size, c->params.lod_cull,
+                       c->box_frame.as<float4>());
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+ShardMap make_shard(uint32_t w, uint32_t h, const rt_shard* sh) {
+    ShardMap m;
+    m.tile_w = sh ? sh->tile_w : w;
+    m.tile_h = sh ? sh->tile_h : h;
+    m.first = sh ? sh->first : 0;
+    m.stride = sh ? sh->stride : 1;
+    m.tiles_x = (w + m.tile_w - 1) / m.tile_w;
+    m.tiles_y = (h + m.tile_h - 1) / m.tile_h;
+    m.n_tiles = m.tiles_x * m.tiles_y;
+    m.n_local = m.first < m.n_tiles ? (m.n_tiles - m.first + m.stride - 1) / m.stride : 0;
+    m.sub_x = (m.tile_w + 7) / 8;
+    m.sub_y = (m.tile_h + 7) / 8;
+    return m;
+}
+
+int zero_stats(rt_ctx* c) {
+    RT_HIP(c, c->stats.reserve(8 * sizeof(unsigned long long)));
+    RT_HIP(c, hipMemsetAsync(c->stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
+    return RT_OK;
+}
+
+int fetch_stats(rt_ctx* c) {
+    unsigned long long v[8];
+    RT_HIP(c, hipMemcpyAsync(v, c->stats.p, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->last_stats.rays = v[0];
+    c->last_stats.primary_hits = v[1];
+    c->last_stats.shadow_rays = v[2];
+    c->last_stats.shadow_hits = v[3];
+    c->last_stats.cells_visited = v[4];
+    c->last_stats.tri_tests = v[5];
+    c->last_stats.box_tests = v[6];
+    return RT_OK;
+}
+
+template <bool WGSL, bool SHADOW>
+void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* op,
+                    uint2* os) {
+    unsigned long long* st = c->stats.as<unsigned long long>();
+    if (stats)
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+    else
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+}
+
+template <bool WGSL, bool ANY>
+void launch_rays(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const float* o, const float* d, uint32_t n,
+                 uint2* out) {
+    unsigned long long* st = c->stats.as<unsigned long long>();
+    if (stats)
+        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+    else
+        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+}
+
+// Stage a host array on the device (or pass a device pointer through).
+int stage_in(rt_ctx* c, DevBuf& buf, const void* src, size_t bytes, const void** dev) {
+    if (is_device_ptr(src)) {
+        *dev = src;
+        return RT_OK;
+    }
+    RT_HIP(c, buf.reserve(bytes));
+    RT_HIP(c, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = buf.p;
+    return RT_OK;
+}
+
+}  // namespace
+
+namespace rt {
+
+int emit_refs_from_csr(rt_ctx* c) {
+    RT_HIP(c, c->cells.reserve((size_t)c->n_cells * sizeof(uint2)));
+    RT_HIP(c, c->refs.reserve(((size_t)c->n_refs * 3 + 3) * sizeof(float4)));
+    hipLaunchKernelGGL(k_emit_cells, dim3((c->n_cells + 255) / 256), dim3(256), 0, c->stream,
+                       c->cell_start.as<uint32_t>(), c->n_cells, c->cells.as<uint2>());
+    RT_HIP(c, hipGetLastError());
+    if (c->n_refs) {
+        hipLaunchKernelGGL(k_emit_refs, dim3((c->n_refs + 255) / 256), dim3(256), 0, c->stream,
+                           c->indices.as<uint32_t>(), c->n_refs, c->tri_v.as<float>(), c->grid_nb, c->nt,
+                           c->refs.as<float4>());
+        RT_HIP(c, hipGetLastError());
+    }
+    return RT_OK;
+}
+
+}  // namespace rt
+
+// ================================================================== lifecycle
+
+extern "C" void rt_default_params(rt_params* p) {
+    if (!p) return;
+    p->finest_cell_size = RT_FINEST_CELL_SIZE;
+    p->max_objects_per_cell = RT_MAX_OBJECTS_PER_CELL;
+    p->max_dda_steps = 200;
+    p->wgsl_compat = 0;
+    p->lod_cull = 1;
+    p->moving_box_count = 3;
+    p->fov = 0.785398f;
+    p->light_direction[0] = 0.5f;
+    p->light_direction[1] = -1.0f;
+    p->light_direction[2] = 0.3f;
+    p->shadow_offset = 0.001f;
+    p->collect_stats = 0;
+}
+
+extern "C" const char* rt_create_error(void) { return g_create_error.c_str(); }
+
+extern "C" int rt_create(rt_ctx** out, int device_id, const rt_params* params) {
+    g_create_error.clear();
+    if (!out) {
+        g_create_error = "rt_create: out is NULL";
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        g_create_error = std::string("rt_create: no HIP device (") + hipGetErrorString(e) + ")";
+        return RT_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        g_create_error = "rt_create: device_id out of range";
+        return RT_ERR_INVALID;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
+        g_create_error = std::string("rt_create: hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return RT_ERR_NO_DEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("rt_create: device is ") + prop.gcnArchName + ", this library holds gfx950 code only";
+        return RT_ERR_NO_DEVICE;
+    }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        g_create_error = std::string("rt_create: hipSetDevice: ") + hipGetErrorString(e);
+        return RT_ERR_NO_DEVICE;
+    }
+    rt_ctx* c = new rt_ctx();
+    c->device = device_id;
+    if (params)
+        c->params = *params;
+    else
+        rt_default_params(&c->params);
+    memset(&c->meta, 0, sizeof(c->meta));
+    memset(&c->last_stats, 0, sizeof(c->last_stats));
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        g_create_error = std::string("rt_create: stream/event creation: ") + hipGetErrorString(e);
+        delete c;
+        return RT_ERR_NO_DEVICE;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return RT_OK;
+}
+
+extern "C" void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
+                      &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
+                      &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->out_p,     &c->out_s,
+                      &c->in_o,      &c->in_d,      &c->stats,      &c->misc};
+    for (DevBuf* b : bufs) b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int rt_set_stream(rt_ctx* c, void* hip_stream) {
+    if (int r = use(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return RT_OK;
+}
+
+extern "C" int rt_sync(rt_ctx* c) {
+    if (int r = use(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_set_collect_stats(rt_ctx* c, int enabled) {
+    if (int r = use(c)) return r;
+    c->params.collect_stats = enabled ? 1u : 0u;
+    return RT_OK;
+}
+
+extern "C" int rt_get_stats(rt_ctx* c, rt_stats* stats) {
+    if (int r = use(c)) return r;
+    if (!stats) return fail(c, RT_ERR_INVALID, "rt_get_stats: stats is NULL");
+    *stats = c->last_stats;
+    return RT_OK;
+}
+
+// reference: src/camera.rs:51-54,76-122
+extern "C" void rt_camera_to_uniform(const float position[3], float yaw, float pitch, float time, float screen_height,
+                                     float fov, int show_grid, CameraUniform* out) {
+    if (!out) return;
+    V3 fwd = normalize(v3(sinf(yaw) * cosf(pitch), sinf(pitch), cosf(yaw) * cosf(pitch)));
+    V3 right = normalize(cross(fwd, v3(0.0f, 1.0f, 0.0f)));
+    memset(out, 0, sizeof(*out));
+    for (int k = 0; k < 3; ++k) out->position[k] = position[k];
+    out->forward[0] = fwd.x, out->forward[1] = fwd.y, out->forward[2] = fwd.z;
+    out->right[0] = right.x, out->right[1] = right.y, out->right[2] = right.z;
+    out->up[0] = 0.0f, out->up[1] = 1.0f, out->up[2] = 0.0f;
+    out->time = time;
+    out->lod_factor = screen_height / (2.0f * tanf(fov / 2.0f));
+    out->min_pixel_size = 2.0f;
+    out->show_grid = show_grid ? 1.0f : 0.0f;
+}
+
+// ================================================================== scene and grid
+
+extern "C" int rt_set_scene(rt_ctx* c, const BoxData* boxes, uint32_t nb, const TriangleData* tris, uint32_t nt) {
+    if (int r = use(c)) return r;
+    if ((nb && !boxes) || (nt && !tris)) return fail(c, RT_ERR_INVALID, "rt_set_scene: NULL array with non-zero count");
+    if ((uint64_t)nb + nt >= 0xFFFFFFF0ull) return fail(c, RT_ERR_LIMIT, "rt_set_scene: more than 2^32-16 objects");
+    c->has_grid = false;
+    c->nb = nb;
+    c->nt = nt;
+    RT_HIP(c, c->boxes.reserve((size_t)nb * sizeof(BoxData) + 16));
+    RT_HIP(c, c->tri_v.reserve((size_t)nt * 9 * sizeof(float) + 16));
+    if (nb) RT_HIP(c, hipMemcpyAsync(c->boxes.p, boxes, (size_t)nb * sizeof(BoxData), hipMemcpyHostToDevice, c->stream));
+    if (nt) {
+        // 80-byte records in, 36-byte vertex records kept: the rest (uv, material) is not geometry
+        RT_HIP(c, c->misc.reserve((size_t)nt * sizeof(TriangleData)));
+        RT_HIP(c, hipMemcpyAsync(c->misc.p, tris, (size_t)nt * sizeof(TriangleData), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_tri_unpack, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->misc.as<TriangleData>(), nt,
+                           c->tri_v.as<float>());
+        RT_HIP(c, hipGetLastError());
+    }
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+static int check_meta(rt_ctx* c, const GridMetadata* meta, size_t n_cells, const char* who) {
+    if (!meta) return fail(c, RT_ERR_INVALID, "%s: meta is NULL", who);
+    const uint32_t* g = meta->grid_sizes[RT_GRID_LEVELS - 1];
+    uint64_t want = (uint64_t)g[0] * g[1] * g[2];
+    if (want == 0 || want > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "%s: fine grid of %llu cells", who, (unsigned long long)want);
+    if (n_cells != (size_t)want)
+        return fail(c, RT_ERR_INVALID, "%s: n_cells=%zu but grid_sizes says %llu", who, n_cells, (unsigned long long)want);
+    if (!(meta->finest_cell_size > 0.0f)) return fail(c, RT_ERR_INVALID, "%s: finest_cell_size must be > 0", who);
+    return RT_OK;
+}
+
+static int install_csr(rt_ctx* c, const GridMetadata* meta, const uint32_t* cell_start, const uint32_t* indices,
+                       size_t n_cells) {
+    uint32_t n_refs = cell_start[n_cells];
+    for (size_t k = 0; k < n_cells; ++k)
+        if (cell_start[k + 1] < cell_start[k]) return fail(c, RT_ERR_INVALID, "cell_start is not non-decreasing at %zu", k);
+    c->meta = *meta;
+    c->grid_nb = c->nb;
+    c->n_cells = (uint32_t)n_cells;
+    c->n_refs = n_refs;
+    RT_HIP(c, c->cell_start.reserve((n_cells + 1) * sizeof(uint32_t)));
+    RT_HIP(c, c->indices.reserve((size_t)n_refs * sizeof(uint32_t) + 16));
+    RT_HIP(c, hipMemcpyAsync(c->cell_start.p, cell_start, (n_cells + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (n_refs)
+        RT_HIP(c, hipMemcpyAsync(c->indices.p, indices, (size_t)n_refs * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (int r = emit_refs_from_csr(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->has_grid = true;
+    return RT_OK;
+}
+
+extern "C" int rt_set_grid_csr(rt_ctx* c, const GridMetadata* meta, const uint32_t* cell_start, const uint32_t* indices) {
+    if (int r = use(c)) return r;
+    if (!meta || !cell_start) return fail(c, RT_ERR_INVALID, "rt_set_grid_csr: NULL argument");
+    const uint32_t* g = meta->grid_sizes[RT_GRID_LEVELS - 1];
+    size_t n_cells = (size_t)g[0] * g[1] * g[2];
+    if (int r = check_meta(c, meta, n_cells, "rt_set_grid_csr")) return r;
+    if (cell_start[n_cells] && !indices) return fail(c, RT_ERR_INVALID, "rt_set_grid_csr: indices is NULL");
+    return install_csr(c, meta, cell_start, indices, n_cells);
+}
+
+// Dense per-cell records -> compact list. Only the count word and the first `count` ids of each
+// record are read, so the untouched tail pages of a multi-gigabyte dense array are never faulted in.
+template <class Cell, uint32_t CAP>
+static int set_grid_dense(rt_ctx* c, const GridMetadata* meta, const Cell* cells, size_t n_cells, const char* who) {
+    if (int r = use(c)) return r;
+    if (!cells) return fail(c, RT_ERR_INVALID, "%s: fine_cells is NULL", who);
+    if (int r = check_meta(c, meta, n_cells, who)) return r;
+    std::vector<uint32_t> start(n_cells + 1);
+    uint64_t acc = 0;
+    for (size_t k = 0; k < n_cells; ++k) {
+        start[k] = (uint32_t)acc;
+        acc += cells[k].count < CAP ? cells[k].count : CAP;  // the shader stops at min(count, cap)
+        if (acc > 0xFFFFFFF0ull) return fail(c, RT_ERR_LIMIT, "%s: more than 2^32-16 references", who);
+    }
+    start[n_cells] = (uint32_t)acc;
+    std::vector<uint32_t> idx((size_t)acc);
+    for (size_t k = 0; k < n_cells; ++k)
+        memcpy(idx.data() + start[k], cells[k].object_indices, (size_t)(start[k + 1] - start[k]) * sizeof(uint32_t));
+    return install_csr(c, meta, start.data(), idx.data(), n_cells);
+}
+
+extern "C" int rt_set_grid_dense(rt_ctx* c, const GridMetadata* meta, const FineCellData* fine_cells, size_t n_cells) {
+    return set_grid_dense<FineCellData, RT_MAX_OBJECTS_PER_CELL>(c, meta, fine_cells, n_cells, "rt_set_grid_dense");
+}
+
+extern "C" int rt_set_grid_dense_tri(rt_ctx* c, const GridMetadata* meta, const TriFineCellData* fine_cells, size_t n_cells) {
+    return set_grid_dense<TriFineCellData, RT_TRI_MAX_TRIANGLES_PER_CELL>(c, meta, fine_cells, n_cells,
+                                                                         "rt_set_grid_dense_tri");
+}
+
+extern "C" int rt_build_grid(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode) {
+    if (int r = use(c)) return r;
+    if (mode != RT_GRID_HIERARCHICAL && mode != RT_GRID_TRIANGLES) return fail(c, RT_ERR_INVALID, "rt_build_grid: bad mode");
+    if (!(cell_size > 0.0f)) cell_size = c->params.finest_cell_size;
+    if (max_per_cell == 0)
+        max_per_cell = mode == RT_GRID_TRIANGLES ? RT_TRI_MAX_TRIANGLES_PER_CELL : c->params.max_objects_per_cell;
+    c->has_grid = false;
+    if (int r = build_grid_device(c, cell_size, max_per_cell, mode)) return r;
+    c->has_grid = true;
+    return RT_OK;
+}
+
+extern "C" int rt_get_grid(rt_ctx* c, GridMetadata* meta, uint32_t* n_cells, uint32_t* n_refs) {
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_get_grid: no grid");
+    if (meta) *meta = c->meta;
+    if (n_cells) *n_cells = c->n_cells;
+    if (n_refs) *n_refs = c->n_refs;
+    return RT_OK;
+}
+
+extern "C" int rt_read_grid_csr(rt_ctx* c, uint32_t* cell_start, uint32_t* indices) {
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_read_grid_csr: no grid");
+    if (cell_start)
+        RT_HIP(c, hipMemcpyAsync(cell_start, c->cell_start.p, ((size_t)c->n_cells + 1) * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, c->stream));
+    if (indices && c->n_refs)
+        RT_HIP(c, hipMemcpyAsync(indices, c->indices.p, (size_t)c->n_refs * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                 c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_update_vertices(rt_ctx* c, const float* xyz9, uint32_t first, uint32_t count) {
+    if (int r = use(c)) return r;
+    if (!xyz9 && count) return fail(c, RT_ERR_INVALID, "rt_update_vertices: xyz9 is NULL");
+    if ((uint64_t)first + count > c->nt) return fail(c, RT_ERR_INVALID, "rt_update_vertices: range beyond %u triangles", c->nt);
+    if (!count) return RT_OK;
+    const bool dev = is_device_ptr(xyz9);
+    RT_HIP(c, hipMemcpyAsync(c->tri_v.as<float>() + 9 * (size_t)first, xyz9, (size_t)count * 9 * sizeof(float),
+                             dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (!dev) RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->has_grid = false;  // cell lists and reference records are stale now
+    return RT_OK;
+}
+
+// ================================================================== tracing
+
+extern "C" int rt_trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height,
+                                const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow) {
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_trace_primary: no grid (call rt_build_grid or rt_set_grid_*)");
+    if (!cam || !out_primary) return fail(c, RT_ERR_INVALID, "rt_trace_primary: NULL camera or output");
+    if (!width || !height) return fail(c, RT_ERR_INVALID, "rt_trace_primary: empty frame");
+    if (shard && (!shard->tile_w || !shard->tile_h || !shard->stride))
+        return fail(c, RT_ERR_INVALID, "rt_trace_primary: shard tile size and stride must be non-zero");
+    const ShardMap m = make_shard(width, height, shard);
+    const size_t n_out = (size_t)m.n_local * m.tile_w * m.tile_h;
+    if (n_out == 0) return RT_OK;
+    const uint64_t waves = (uint64_t)m.n_local * m.sub_x * m.sub_y;
+    if (waves > 0x3FFFFFFFull) return fail(c, RT_ERR_LIMIT, "rt_trace_primary: frame too large");
+
+    const bool host_p = !is_device_ptr(out_primary);
+    const bool host_s = out_shadow && !is_device_ptr(out_shadow);
+    uint2* op = reinterpret_cast<uint2*>(out_primary);
+    uint2* os = reinterpret_cast<uint2*>(out_shadow);
+    if (host_p) {
+        RT_HIP(c, c->out_p.reserve(n_out * sizeof(uint2)));
+        op = c->out_p.as<uint2>();
+    }
+    if (host_s) {
+        RT_HIP(c, c->out_s.reserve(n_out * sizeof(uint2)));
+        os = c->out_s.as<uint2>();
+    }
+    if (int r = update_box_frame(c, cam)) return r;
+    const bool stats = c->params.collect_stats != 0;
+    if (stats)
+        if (int r = zero_stats(c)) return r;
+
+    const DevScene s = make_scene(c);
+    const DevFrame f = make_frame(c, cam, width, height);
+    const dim3 grid((uint32_t)((waves + 3) / 4));
+    const bool wgsl = c->params.wgsl_compat != 0;
+    if (out_shadow) {
+        if (wgsl)
+            launch_primary<true, true>(c, stats, grid, s, f, m, op, os);
+        else
+            launch_primary<false, true>(c, stats, grid, s, f, m, op, os);
+    } else {
+        if (wgsl)
+            launch_primary<true, false>(c, stats, grid, s, f, m, op, os);
+        else
+            launch_primary<false, false>(c, stats, grid, s, f, m, op, os);
+    }
+    RT_HIP(c, hipGetLastError());
+    if (host_p) RT_HIP(c, hipMemcpyAsync(out_primary, op, n_out * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+    if (host_s) RT_HIP(c, hipMemcpyAsync(out_shadow, os, n_out * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+    if (stats) {
+        if (int r = fetch_stats(c)) return r;
+    } else if (host_p || host_s) {
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_trace_rays(rt_ctx* c, const CameraUniform* cam, const float* origins, const float* dirs, uint32_t n,
+                             rt_hit* out, int any_hit) {
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_trace_rays: no grid (call rt_build_grid or rt_set_grid_*)");
+    if (n == 0) return RT_OK;
+    if (!origins || !dirs || !out) return fail(c, RT_ERR_INVALID, "rt_trace_rays: NULL argument");
+    const void *d_o, *d_d;
+    if (int r = stage_in(c, c->in_o, origins, (size_t)n * 3 * sizeof(float), &d_o)) return r;
+    if (int r = stage_in(c, c->in_d, dirs, (size_t)n * 3 * sizeof(float), &d_d)) return r;
+    const bool host_out = !is_device_ptr(out);
+    uint2* d_out = reinterpret_cast<uint2*>(out);
+    if (host_out) {
+        RT_HIP(c, c->out_p.reserve((size_t)n * sizeof(uint2)));
+        d_out = c->out_p.as<uint2>();
+    }
+    if (int r = update_box_frame(c, cam)) return r;
+    const bool stats = c->params.collect_stats != 0;
+    if (stats)
+        if (int r = zero_stats(c)) return r;
+    const DevScene s = make_scene(c);
+    const dim3 grid((n + 255) / 256);
+    const bool wgsl = c->params.wgsl_compat != 0;
+    const float* fo = static_cast<const float*>(d_o);
+    const float* fd = static_cast<const float*>(d_d);
+    if (any_hit) {
+        if (wgsl)
+            launch_rays<true, true>(c, stats, grid, s, fo, fd, n, d_out);
+        else
+            launch_rays<false, true>(c, stats, grid, s, fo, fd, n, d_out);
+    } else {
+        if (wgsl)
+            launch_rays<true, false>(c, stats, grid, s, fo, fd, n, d_out);
+        else
+            launch_rays<false, false>(c, stats, grid, s, fo, fd, n, d_out);
+    }
+    RT_HIP(c, hipGetLastError());
+    if (host_out) RT_HIP(c, hipMemcpyAsync(out, d_out, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+    if (stats) {
+        if (int r = fetch_stats(c)) return r;
+    } else {
+        // staged inputs must stay untouched until the kernel has read them
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_assemble_tiles(rt_ctx* c, const rt_hit* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+                                 uint32_t tile_h, uint32_t n_ranks, rt_hit* image) {
+    if (int r = use(c)) return r;
+    if (!gathered || !image || !width || !height || !tile_w || !tile_h || !n_ranks)
+        return fail(c, RT_ERR_INVALID, "rt_assemble_tiles: NULL or zero argument");
+    if (!is_device_ptr(gathered) || !is_device_ptr(image))
+        return fail(c, RT_ERR_INVALID, "rt_assemble_tiles: both buffers must be device memory");
+    const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
+    const size_t per_rank = (size_t)((tiles_x * tiles_y + n_ranks - 1) / n_ranks) * tile_w * tile_h;
+    hipLaunchKernelGGL(k_assemble, dim3((width + 255) / 256, height), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint2*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks,
+                       per_rank, reinterpret_cast<uint2*>(image));
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_debug_pixel(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height, uint32_t px,
+                              uint32_t py, RayDebugInfo* info) {
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_debug_pixel: no grid");
+    if (!cam || !info || px >= width || py >= height) return fail(c, RT_ERR_INVALID, "rt_debug_pixel: bad argument");
+    if (int r = update_box_frame(c, cam)) return r;
+    RT_HIP(c, c->misc.reserve(sizeof(RayDebugInfo)));
+    const DevScene s = make_scene(c);
+    const DevFrame f = make_frame(c, cam, width, height);
+    if (c->params.wgsl_compat)
+        hipLaunchKernelGGL(k_debug_pixel<true>, dim3(1), dim3(64), 0, c->stream, s, f, px, py, c->misc.as<float>());
+    else
+        hipLaunchKernelGGL(k_debug_pixel<false>, dim3(1), dim3(64), 0, c->stream, s, f, px, py, c->misc.as<float>());
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(info, c->misc.p, sizeof(RayDebugInfo), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+// ================================================================== primitive routines, all pairs
+
+extern "C" int rt_intersect_aabb_pairs(rt_ctx* c, const float* origins, const float* dirs, uint32_t n_rays,
+                                       const float* box_min, const float* box_max, uint32_t n_prims, float* out_t) {
+    if (int r = use(c)) return r;
+    const size_t n = (size_t)n_rays * n_prims;
+    if (n == 0) return RT_OK;
+    if (!origins || !dirs || !box_min || !box_max || !out_t) return fail(c, RT_ERR_INVALID, "rt_intersect_aabb_pairs: NULL argument");
+    if (n > 0x7FFFFFFFull * 256) return fail(c, RT_ERR_LIMIT, "rt_intersect_aabb_pairs: too many pairs");
+    const size_t rb = (size_t)n_rays * 12, pb = (size_t)n_prims * 12;
+    RT_HIP(c, c->misc.reserve(2 * rb + 2 * pb + n * sizeof(float) + 64));
+    char* base = c->misc.as<char>();
+    float *d_o = (float*)base, *d_d = (float*)(base + rb), *d_mn = (float*)(base + 2 * rb),
+          *d_mx = (float*)(base + 2 * rb + pb), *d_out = (float*)(base + 2 * rb + 2 * pb);
+    RT_HIP(c, hipMemcpyAsync(d_o, origins, rb, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(d_d, dirs, rb, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(d_mn, box_min, pb, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(d_mx, box_max, pb, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((uint32_t)((n + 255) / 256));
+    if (c->params.wgsl_compat)
+        hipLaunchKernelGGL(k_aabb_pairs<true>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_mn, d_mx, n_prims, d_out);
+    else
+        hipLaunchKernelGGL(k_aabb_pairs<false>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_mn, d_mx, n_prims, d_out);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(out_t, d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_intersect_tri_pairs(rt_ctx* c, const float* origins, const float* dirs, uint32_t n_rays,
+                                      const float* v012, uint32_t n_prims, float* out_t) {
+    if (int r = use(c)) return r;
+    const size_t n = (size_t)n_rays * n_prims;
+    if (n == 0) return RT_OK;
+    if (!origins || !dirs || !v012 || !out_t) return fail(c, RT_ERR_INVALID, "rt_intersect_tri_pairs: NULL argument");
+    if (n > 0x7FFFFFFFull * 256) return fail(c, RT_ERR_LIMIT, "rt_intersect_tri_pairs: too many pairs");
+    const size_t rb = (size_t)n_rays * 12, pb = (size_t)n_prims * 36;
+    RT_HIP(c, c->misc.reserve(2 * rb + pb + n * sizeof(float) + 64));
+    char* base = c->misc.as<char>();
+    float *d_o = (float*)base, *d_d = (float*)(base + rb), *d_v = (float*)(base + 2 * rb),
+          *d_out = (float*)(base + 2 * rb + pb);
+    RT_HIP(c, hipMemcpyAsync(d_o, origins, rb, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(d_d, dirs, rb, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(d_v, v012, pb, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((uint32_t)((n + 255) / 256));
+    if (c->params.wgsl_compat)
+        hipLaunchKernelGGL(k_tri_pairs<true>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_v, n_prims, d_out);
+    else
+        hipLaunchKernelGGL(k_tri_pairs<false>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_v, n_prims, d_out);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(out_t, d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+// ================================================================== timing
+
+extern "C" int rt_timer_begin(rt_ctx* c) {
+    if (int r = use(c)) return r;
+    RT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_timer_end(rt_ctx* c, float* elapsed_ms) {
+    if (int r = use(c)) return r;
+    RT_HIP(c, hipEventRecord(c->ev1, c->stream));
+    RT_HIP(c, hipEventSynchronize(c->ev1));
+    float ms = 0.0f;
+    RT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return RT_OK;
+}

@@ -1,0 +1,315 @@
+// On-GPU grid binning: the device counterpart of HierarchicalGrid::build (src/grid.rs:110-216)
+// and TriangleGrid::build (src/grid_triangles.rs:29-124). Same bounds, same dimensions, same
+// per-object cell ranges, ids in ascending order inside every cell, inserts beyond the per-cell
+// cap dropped (i.e. the lowest `cap` ids survive). The three coarse count levels of the
+// reference are not produced: its shader never reads them (raytracer_unified.wgsl:134 is the
+// only mention).
+//
+// Passes: bounds reduction -> per-cell counts (atomics) -> exclusive scan -> fill (atomics,
+// arbitrary order) -> per-cell sort by id -> cap + compaction -> 48-byte reference records.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+
+#include "rt_internal.hpp"
+
+using namespace rt;
+
+namespace {
+
+struct BinGrid {
+    float bmin[3];
+    float cell;
+    uint32_t gx, gy, gz;
+    uint32_t nb, nt;
+    int tri_mode;
+};
+
+// Bounds of object `id` (boxes first, then triangles): src/types.rs:110-115, 235-244.
+__device__ inline void object_bounds(const BoxData* boxes, const float* tri_v, uint32_t nb, uint32_t id, V3& mn, V3& mx) {
+    if (id < nb) {
+        mn = ld3(boxes[id].min);
+        mx = ld3(boxes[id].max);
+    } else {
+        const float* v = tri_v + 9 * (size_t)(id - nb);
+        V3 a = ld3(v), b = ld3(v + 3), c = ld3(v + 6);
+        mn = vmin(vmin(a, b), c);
+        mx = vmax(vmax(a, b), c);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bounds_partial(const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                                                        uint32_t nb, uint32_t total, float* __restrict__ partial) {
+    __shared__ float red[6][256];
+    V3 mn = v3(INFINITY, INFINITY, INFINITY), mx = v3(-INFINITY, -INFINITY, -INFINITY);
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        V3 a, b;
+        object_bounds(boxes, tri_v, nb, id, a, b);
+        mn = vmin(mn, a);
+        mx = vmax(mx, b);
+    }
+    const uint32_t t = threadIdx.x;
+    red[0][t] = mn.x, red[1][t] = mn.y, red[2][t] = mn.z;
+    red[3][t] = mx.x, red[4][t] = mx.y, red[5][t] = mx.z;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            for (int k = 0; k < 3; ++k) red[k][t] = fminf(red[k][t], red[k][t + s]);
+            for (int k = 3; k < 6; ++k) red[k][t] = fmaxf(red[k][t], red[k][t + s]);
+        }
+        __syncthreads();
+    }
+    if (t < 6) partial[blockIdx.x * 6 + t] = red[t][0];
+}
+
+__global__ void k_bounds_final(const float* __restrict__ partial, uint32_t n_blocks, float* __restrict__ out6) {
+    const uint32_t k = threadIdx.x;
+    if (k >= 6) return;
+    float v = partial[k];
+    for (uint32_t b = 1; b < n_blocks; ++b) v = k < 3 ? fminf(v, partial[b * 6 + k]) : fmaxf(v, partial[b * 6 + k]);
+    out6[k] = v;
+}
+
+struct Range3 {
+    int lo[3], hi[3];  // inclusive, empty when lo > hi
+};
+
+// src/grid.rs:218-237,292-299 (clamp at 0, `as u32`, cells outside the grid skipped) and
+// src/grid_triangles.rs:171-209 (`as i32`, loops clamped to the grid).
+__device__ inline Range3 cell_range(const BinGrid& g, V3 omin, V3 omax) {
+    const V3 bmin = v3(g.bmin[0], g.bmin[1], g.bmin[2]);
+    const V3 rmin = omin - bmin, rmax = omax - bmin;
+    const float lo_f[3] = {floorf(rmin.x / g.cell), floorf(rmin.y / g.cell), floorf(rmin.z / g.cell)};
+    const float hi_f[3] = {floorf(rmax.x / g.cell), floorf(rmax.y / g.cell), floorf(rmax.z / g.cell)};
+    const uint32_t dims[3] = {g.gx, g.gy, g.gz};
+    Range3 r;
+    for (int k = 0; k < 3; ++k) {
+        long long lo, hi;
+        if (g.tri_mode) {
+            lo = f2i_sat(lo_f[k]);
+            hi = f2i_sat(hi_f[k]);
+            if (lo < 0) lo = 0;
+        } else {
+            lo = f2u_sat(fmaxf(lo_f[k], 0.0f));
+            hi = f2u_sat(fmaxf(hi_f[k], 0.0f));
+        }
+        if (hi > (long long)dims[k] - 1) hi = (long long)dims[k] - 1;
+        if (lo > hi) {  // empty: normalise so the loops below do nothing
+            lo = 1;
+            hi = 0;
+        }
+        r.lo[k] = (int)lo;
+        r.hi[k] = (int)hi;
+    }
+    return r;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                                             uint32_t* __restrict__ counts, const uint32_t* __restrict__ tmp_start,
+                                             uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_cell) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= g.nb + g.nt) return;
+    V3 mn, mx;
+    object_bounds(boxes, tri_v, g.nb, id, mn, mx);
+    const Range3 r = cell_range(g, mn, mx);
+    for (int z = r.lo[2]; z <= r.hi[2]; ++z)
+        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
+            for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
+                const uint32_t c = (uint32_t)x + (uint32_t)y * g.gx + (uint32_t)z * g.gx * g.gy;
+                const uint32_t slot = atomicAdd(&counts[c], 1u);
+                if (FILL) {
+                    const uint32_t dst = tmp_start[c] + slot;
+                    tmp_ids[dst] = id;
+                    tmp_cell[dst] = c;
+                }
+            }
+}
+
+__global__ void k_clamp_counts(const uint32_t* __restrict__ counts, uint32_t n_cells, uint32_t cap,
+                               uint32_t* __restrict__ clamped) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cells) clamped[c] = counts[c] < cap ? counts[c] : cap;
+    if (c == n_cells) clamped[c] = 0;
+}
+
+__global__ void k_compact(const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ tmp_cell,
+                          const uint32_t* __restrict__ tmp_start, const uint32_t* __restrict__ final_start, uint32_t n_tmp,
+                          uint32_t cap, uint32_t* __restrict__ indices) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_tmp) return;
+    const uint32_t c = tmp_cell[r];
+    const uint32_t j = r - tmp_start[c];
+    if (j < cap) indices[final_start[c] + j] = sorted[r];
+}
+
+}  // namespace
+
+namespace rt {
+
+int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode) {
+    const bool tri_mode = mode == RT_GRID_TRIANGLES;
+    const uint32_t nb = tri_mode ? 0u : c->nb;
+    const uint32_t nt = c->nt;
+    const uint32_t total = nb + nt;
+    hipStream_t st = c->stream;
+
+    // ---- bounds: union of all object bounds, padded by 1.0 (src/grid.rs:112-134; src/grid_triangles.rs:30-55)
+    V3 bmin = v3(-1.0f, -1.0f, -1.0f), bmax = v3(1.0f, 1.0f, 1.0f);
+    const bool tri_empty = tri_mode && nt == 0;
+    if (total > 0) {
+        const uint32_t blocks = std::min<uint32_t>((total + 255) / 256, 1024u);
+        RT_HIP(c, c->b_partial.reserve(((size_t)blocks + 1) * 6 * sizeof(float)));
+        float* partial = c->b_partial.as<float>();
+        float* out6 = partial + (size_t)blocks * 6;
+        hipLaunchKernelGGL(k_bounds_partial, dim3(blocks), dim3(256), 0, st, c->boxes.as<BoxData>(), c->tri_v.as<float>(),
+                           nb, total, partial);
+        hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, st, partial, blocks, out6);
+        RT_HIP(c, hipGetLastError());
+        float h[6];
+        RT_HIP(c, hipMemcpyAsync(h, out6, sizeof(h), hipMemcpyDeviceToHost, st));
+        RT_HIP(c, hipStreamSynchronize(st));
+        bmin = v3(h[0], h[1], h[2]);
+        bmax = v3(h[3], h[4], h[5]);
+    }
+    if (!tri_empty) {
+        bmin = bmin - v3(1.0f, 1.0f, 1.0f);
+        bmax = bmax + v3(1.0f, 1.0f, 1.0f);
+    }
+
+    // ---- dimensions (src/grid.rs:9-16; src/grid_triangles.rs:126-139)
+    uint64_t dims[3];
+    {
+        const V3 e = bmax - bmin;
+        const float ext[3] = {e.x, e.y, e.z};
+        const float div = tri_mode ? fmaxf(cell_size, RT_TRI_MIN_CELL_SIZE) : cell_size;
+        for (int k = 0; k < 3; ++k) {
+            float q = ceilf(ext[k] / div);
+            uint64_t v = !(q > 0.0f) ? 0ull : (q >= 18446744073709551616.0f ? UINT64_MAX : (uint64_t)q);
+            if (tri_mode) v = std::min<uint64_t>(std::max<uint64_t>(v, 1), RT_TRI_MAX_GRID_DIM);
+            if (tri_empty) v = 1;
+            dims[k] = v;
+        }
+    }
+    if (dims[0] == 0 || dims[1] == 0 || dims[2] == 0 || dims[0] > 0x7FFFFFFF || dims[1] > 0x7FFFFFFF ||
+        dims[2] > 0x7FFFFFFF || dims[0] * dims[1] > 0x7FFFFFFFull || dims[0] * dims[1] * dims[2] > 0x7FFFFFFFull)
+        return fail(c, RT_ERR_LIMIT, "rt_build_grid: grid of %llu x %llu x %llu cells", (unsigned long long)dims[0],
+                    (unsigned long long)dims[1], (unsigned long long)dims[2]);
+    const uint32_t n_cells = (uint32_t)(dims[0] * dims[1] * dims[2]);
+
+    GridMetadata meta;
+    memset(&meta, 0, sizeof(meta));
+    meta.bounds_min[0] = bmin.x, meta.bounds_min[1] = bmin.y, meta.bounds_min[2] = bmin.z;
+    meta.bounds_max[0] = bmax.x, meta.bounds_max[1] = bmax.y, meta.bounds_max[2] = bmax.z;
+    meta.num_levels = RT_GRID_LEVELS;
+    meta.finest_cell_size = cell_size;
+    for (int k = 0; k < 3; ++k) meta.grid_sizes[RT_GRID_LEVELS - 1][k] = (uint32_t)dims[k];
+    if (!tri_empty) {
+        // coarse level dimensions are reported (src/grid.rs:302-322); their counts are not built
+        for (uint32_t level = 0; level + 1 < RT_GRID_LEVELS; ++level) {
+            const float cs = cell_size * (float)(1u << (RT_GRID_LEVELS - 1 - level));
+            const float div = tri_mode ? fmaxf(cs, RT_TRI_MIN_CELL_SIZE) : cs;
+            const V3 e = bmax - bmin;
+            const float ext[3] = {e.x, e.y, e.z};
+            for (int k = 0; k < 3; ++k) {
+                float q = ceilf(ext[k] / div);
+                uint64_t v = !(q > 0.0f) ? 0ull : (q >= 4294967296.0f ? 0xFFFFFFFFull : (uint64_t)q);
+                if (tri_mode) v = std::min<uint64_t>(std::max<uint64_t>(v, 1), RT_TRI_MAX_GRID_DIM);
+                meta.grid_sizes[level][k] = (uint32_t)v;
+            }
+        }
+    }
+
+    BinGrid g;
+    g.bmin[0] = bmin.x, g.bmin[1] = bmin.y, g.bmin[2] = bmin.z;
+    g.cell = cell_size;
+    g.gx = (uint32_t)dims[0], g.gy = (uint32_t)dims[1], g.gz = (uint32_t)dims[2];
+    g.nb = nb, g.nt = nt;
+    g.tri_mode = tri_mode ? 1 : 0;
+
+    // ---- count
+    const size_t cell_bytes = ((size_t)n_cells + 1) * sizeof(uint32_t);
+    RT_HIP(c, c->b_counts.reserve(cell_bytes));
+    RT_HIP(c, c->b_tmp_start.reserve(cell_bytes));
+    RT_HIP(c, c->b_cursor.reserve(cell_bytes));
+    RT_HIP(c, c->cell_start.reserve(cell_bytes));
+    uint32_t* counts = c->b_counts.as<uint32_t>();
+    uint32_t* tmp_start = c->b_tmp_start.as<uint32_t>();
+    uint32_t* cursor = c->b_cursor.as<uint32_t>();
+    uint32_t* final_start = c->cell_start.as<uint32_t>();
+    RT_HIP(c, hipMemsetAsync(counts, 0, cell_bytes, st));
+    RT_HIP(c, hipMemsetAsync(cursor, 0, cell_bytes, st));
+    const dim3 obj_grid((total + 255) / 256);
+    if (total) {
+        hipLaunchKernelGGL(k_bin<false>, obj_grid, dim3(256), 0, st, g, c->boxes.as<BoxData>(), c->tri_v.as<float>(), counts,
+                           (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        RT_HIP(c, hipGetLastError());
+    }
+
+    // ---- scan of the uncapped counts: where each cell's unsorted ids go
+    size_t scan_bytes = 0;
+    RT_HIP(c, rocprim::exclusive_scan(nullptr, scan_bytes, counts, tmp_start, 0u, (size_t)n_cells + 1, rocprim::plus<uint32_t>(), st));
+    RT_HIP(c, c->b_scan_tmp.reserve(scan_bytes + 256));
+    RT_HIP(c, rocprim::exclusive_scan(c->b_scan_tmp.p, scan_bytes, counts, tmp_start, 0u, (size_t)n_cells + 1,
+                                      rocprim::plus<uint32_t>(), st));
+    uint32_t n_tmp = 0;
+    RT_HIP(c, hipMemcpyAsync(&n_tmp, tmp_start + n_cells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RT_HIP(c, hipStreamSynchronize(st));
+    if (n_tmp > 0xFFFFFFF0u / 2) return fail(c, RT_ERR_LIMIT, "rt_build_grid: %u cell references", n_tmp);
+
+    uint32_t n_refs = 0;
+    if (n_tmp) {
+        // ---- fill (arbitrary order inside a cell), then sort every cell's ids ascending
+        const size_t ref_bytes = (size_t)n_tmp * sizeof(uint32_t);
+        RT_HIP(c, c->b_tmp_ids.reserve(ref_bytes));
+        RT_HIP(c, c->b_tmp_sorted.reserve(ref_bytes));
+        RT_HIP(c, c->b_tmp_cell.reserve(ref_bytes));
+        uint32_t* tmp_ids = c->b_tmp_ids.as<uint32_t>();
+        uint32_t* tmp_sorted = c->b_tmp_sorted.as<uint32_t>();
+        uint32_t* tmp_cell = c->b_tmp_cell.as<uint32_t>();
+        hipLaunchKernelGGL(k_bin<true>, obj_grid, dim3(256), 0, st, g, c->boxes.as<BoxData>(), c->tri_v.as<float>(), cursor,
+                           (const uint32_t*)tmp_start, tmp_ids, tmp_cell);
+        RT_HIP(c, hipGetLastError());
+        size_t sort_bytes = 0;
+        RT_HIP(c, rocprim::segmented_radix_sort_keys(nullptr, sort_bytes, tmp_ids, tmp_sorted, n_tmp, n_cells, tmp_start,
+                                                     tmp_start + 1, 0, 32, st));
+        RT_HIP(c, c->b_scan_tmp.reserve(sort_bytes + 256));
+        RT_HIP(c, rocprim::segmented_radix_sort_keys(c->b_scan_tmp.p, sort_bytes, tmp_ids, tmp_sorted, n_tmp, n_cells,
+                                                     tmp_start, tmp_start + 1, 0, 32, st));
+
+        // ---- cap: keep the first max_per_cell ids of every cell, compact
+        hipLaunchKernelGGL(k_clamp_counts, dim3((n_cells + 1 + 255) / 256), dim3(256), 0, st, counts, n_cells, max_per_cell,
+                           cursor);
+        RT_HIP(c, hipGetLastError());
+        RT_HIP(c, rocprim::exclusive_scan(nullptr, scan_bytes, cursor, final_start, 0u, (size_t)n_cells + 1,
+                                          rocprim::plus<uint32_t>(), st));
+        RT_HIP(c, c->b_scan_tmp.reserve(scan_bytes + 256));
+        RT_HIP(c, rocprim::exclusive_scan(c->b_scan_tmp.p, scan_bytes, cursor, final_start, 0u, (size_t)n_cells + 1,
+                                          rocprim::plus<uint32_t>(), st));
+        RT_HIP(c, hipMemcpyAsync(&n_refs, final_start + n_cells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RT_HIP(c, hipStreamSynchronize(st));
+        RT_HIP(c, c->indices.reserve((size_t)n_refs * sizeof(uint32_t) + 16));
+        hipLaunchKernelGGL(k_compact, dim3((n_tmp + 255) / 256), dim3(256), 0, st, (const uint32_t*)tmp_sorted,
+                           (const uint32_t*)tmp_cell, (const uint32_t*)tmp_start, (const uint32_t*)final_start, n_tmp,
+                           max_per_cell, c->indices.as<uint32_t>());
+        RT_HIP(c, hipGetLastError());
+    } else {
+        RT_HIP(c, hipMemsetAsync(final_start, 0, cell_bytes, st));
+        RT_HIP(c, c->indices.reserve(16));
+    }
+
+    c->meta = meta;
+    c->n_cells = n_cells;
+    c->n_refs = n_refs;
+    // a triangle-only grid numbers its triangles from 0 and knows no boxes (src/grid_triangles.rs:92-99)
+    c->grid_nb = nb;
+    if (int r = emit_refs_from_csr(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+}  // namespace rt

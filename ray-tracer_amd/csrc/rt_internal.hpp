@@ -1,0 +1,119 @@
+// Library-internal context and helpers shared by rt_api.hip and rt_build.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/rt_mi355.h"
+#include "rt_trace.hpp"
+
+namespace rt {
+
+// Growable device allocation. Capacity only grows; contents are NOT preserved across a grow.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+}  // namespace rt
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // stream in use (own_stream or the caller's)
+    rt_params params;
+    std::string err;
+
+    // scene
+    uint32_t nb = 0, nt = 0;
+    uint32_t grid_nb = 0;  // boxes numbered ahead of the triangles in the current grid's ids (0 for a triangle-only grid)
+    rt::DevBuf boxes;  // BoxData[nb]
+    rt::DevBuf tri_v;  // float[nt*9]: v0,v1,v2
+
+    // grid
+    bool has_grid = false;
+    GridMetadata meta;
+    uint32_t n_cells = 0, n_refs = 0;
+    rt::DevBuf cell_start;  // u32[n_cells+1]
+    rt::DevBuf indices;     // u32[n_refs]
+    rt::DevBuf cells;       // uint2[n_cells]
+    rt::DevBuf refs;        // float4[3*n_refs]
+    rt::DevBuf box_frame;   // float4[4*nb]
+
+    // binning scratch
+    rt::DevBuf b_partial, b_counts, b_tmp_start, b_cursor, b_tmp_ids, b_tmp_sorted, b_tmp_cell, b_scan_tmp, b_flags;
+
+    // per-call scratch
+    rt::DevBuf out_p, out_s, in_o, in_d, stats, misc;
+    rt_stats last_stats;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace rt {
+
+inline int fail(rt_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define RT_HIP(c, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return rt::fail((c), RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                            __FILE__, __LINE__);                                                     \
+    } while (0)
+
+// true when p points to device-accessible memory allocated through HIP
+inline bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// implemented in rt_build.hip
+int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode);
+// implemented in rt_api.hip: (cell_start, indices) on device -> cells + refs records
+int emit_refs_from_csr(rt_ctx* c);
+
+}  // namespace rt

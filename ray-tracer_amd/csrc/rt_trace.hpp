@@ -1,0 +1,331 @@
+// Device side of the trace path: primary-ray generation, 3D-DDA over the uniform grid,
+// per-cell candidate tests, closest-hit / any-hit resolution, shadow-ray generation.
+//
+// Replaces the geometry part of the reference's compute shader
+// (src/raytracer_unified.wgsl:430-588 trace_ray, :625-653 ray generation).
+//
+// Data layout in HBM (built by rt_build.hip / the gather kernels in rt_api.hip):
+//   cells[c]      uint2 (first ref, ref count) per fine grid cell, c = x + y*gx + z*gx*gy
+//   refs[3*r..]   one 48-byte record per (cell, object) reference, stored in cell order so a
+//                 cell's candidates are contiguous:  (v0.xyz, id bits) (e1.xyz, 0) (e2.xyz, 0)
+//                 for a triangle, (0,0,0, id bits) for a box (box data is per frame, below)
+//   box_frame[4*b..] per box, recomputed each frame: (lo.xyz, flag bits) (hi.xyz, 0)
+//                 (centre.xyz, 0) (half.xyz, 0) with lo/hi = interpolated centre -/+ half
+#pragma once
+
+#include "rt_math.hpp"
+
+namespace rt {
+
+constexpr uint32_t MISS = 0xFFFFFFFFu;
+constexpr uint32_t REF_INVALID = 0xFFFFFFFEu;  // reference to a triangle index >= num_triangles: skipped
+constexpr uint32_t BOX_CULLED_GRID = 1u;       // LOD cull outcome when met through a grid cell
+constexpr uint32_t BOX_CULLED_PREPASS = 2u;    // LOD cull outcome in the moving-box pre-pass
+
+struct DevScene {
+    const float4* refs;
+    const uint2* cells;
+    const float4* box_frame;
+    uint32_t nb, nt, n_cells, n_refs;
+    uint32_t gx, gy, gz;
+    uint32_t max_per_cell, max_steps, moving_start;
+    float bmin[3], bmax[3];
+    float cell_size;
+};
+
+struct DevFrame {
+    float cam_pos[3], fwd[3], right[3], up[3];
+    float fov_scale;      // tan(fov), evaluated once on the host
+    float shadow_dir[3];  // -normalize(light_direction), evaluated once on the host
+    float shadow_offset;
+    uint32_t width, height;
+};
+
+struct ShardMap {
+    uint32_t tile_w, tile_h, first, stride, tiles_x, tiles_y, n_tiles, n_local;
+    uint32_t sub_x, sub_y;  // 8x8 sub-tiles per tile
+};
+
+struct Counters {
+    uint32_t cells, tri, box, steps;
+};
+
+struct HitRec {
+    float t;
+    uint32_t id;
+    uint32_t ref;  // index of the winning reference record (triangles) - used to rebuild the normal
+};
+
+// One ray through the grid. ANY: stop at the first accepted intersection.
+// Returns true on a hit. Mirrors raytracer_unified.wgsl:430-588 statement by statement.
+template <bool WGSL, bool ANY, bool STATS>
+__device__ inline bool trace_ray(const DevScene& s, V3 o, V3 d, HitRec& out, Counters& ctr) {
+    bool hit = false;
+    float closest = 1e10f;
+    uint32_t best_id = MISS, best_ref = MISS;
+    const V3 inv = v3(safe_inv<WGSL>(d.x), safe_inv<WGSL>(d.y), safe_inv<WGSL>(d.z));
+    ctr.steps = 0;
+
+    // moving boxes are tested directly, before the grid (:442-461)
+    for (uint32_t i = s.moving_start; i < s.nb; ++i) {
+        ctr.steps++;
+        const float4 b0 = s.box_frame[4 * i], b1 = s.box_frame[4 * i + 1];
+        if (!(__float_as_uint(b0.w) & BOX_CULLED_PREPASS)) {
+            if (STATS) ctr.box++;
+            float t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
+            if (t >= 0.0f && t < closest) {
+                closest = t;
+                best_id = i;
+                best_ref = MISS;
+                hit = true;
+                if (ANY) {
+                    out = HitRec{closest, best_id, best_ref};
+                    return true;
+                }
+            }
+        }
+    }
+
+    const V3 bmin = v3(s.bmin[0], s.bmin[1], s.bmin[2]), bmax = v3(s.bmax[0], s.bmax[1], s.bmax[2]);
+    const float cs = s.cell_size;
+
+    // entry point (:467-489); a ray that misses the grid reports no hit at all
+    V3 pos = o;
+    float t_off = 0.0f;
+    if (pos.x < bmin.x || pos.x > bmax.x || pos.y < bmin.y || pos.y > bmax.y || pos.z < bmin.z || pos.z > bmax.z) {
+        float t_entry = slab(o, inv, bmin, bmax);
+        if (t_entry < 0.0f) return false;
+        t_off = t_entry + 0.001f;
+        pos = o + d * t_off;
+        const float e = 0.0001f;
+        pos = vmin(vmax(pos, bmin + v3(e, e, e)), bmax - v3(e, e, e));
+    }
+
+    // DDA set-up (:492-517)
+    uint32_t cx, cy, cz;
+    {
+        V3 rel = pos - bmin;
+        float ics = 1.0f / fmaxf(cs, 1e-8f);
+        cx = f2u_sat(fmaxf(0.0f, floorf(rel.x * ics)));
+        cy = f2u_sat(fmaxf(0.0f, floorf(rel.y * ics)));
+        cz = f2u_sat(fmaxf(0.0f, floorf(rel.z * ics)));
+    }
+    const int sx = d.x >= 0.0f ? 1 : -1, sy = d.y >= 0.0f ? 1 : -1, sz = d.z >= 0.0f ? 1 : -1;
+    V3 cell_world = bmin + v3((float)cx, (float)cy, (float)cz) * cs;
+    V3 next_b = cell_world + v3(sx > 0 ? cs : 0.0f, sy > 0 ? cs : 0.0f, sz > 0 ? cs : 0.0f);
+    const V3 t_delta = vabs(inv * cs);
+    V3 t_max = v3(t_off, t_off, t_off) + (next_b - pos) * inv;
+    {
+        float fl = t_off + 0.00001f;
+        t_max = vmax(t_max, v3(fl, fl, fl));
+    }
+
+    // traversal (:520-588)
+    for (uint32_t i = 0; i < s.max_steps; ++i) {
+        ctr.steps++;
+        if (STATS) ctr.cells++;
+        // flattened index in wrapping u32 arithmetic; past the array = empty cell
+        uint32_t idx = cx + cy * s.gx + cz * s.gx * s.gy;
+        uint2 cell = make_uint2(0u, 0u);
+        if (idx < s.n_cells) cell = s.cells[idx];
+        uint32_t n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t r = cell.x + j;
+            const float4 q0 = s.refs[3 * r];
+            const uint32_t id = __float_as_uint(q0.w);
+            float t = -1.0f;
+            if (id < s.nb) {
+                const float4 b0 = s.box_frame[4 * id], b1 = s.box_frame[4 * id + 1];
+                if (!(__float_as_uint(b0.w) & BOX_CULLED_GRID)) {
+                    if (STATS) ctr.box++;
+                    t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
+                }
+                if (t >= 0.0f && t < closest) {
+                    closest = t;
+                    best_id = id;
+                    best_ref = MISS;
+                    hit = true;
+                    if (ANY) {
+                        out = HitRec{closest, best_id, best_ref};
+                        return true;
+                    }
+                }
+            } else if (id != REF_INVALID) {
+                if (STATS) ctr.tri++;
+                const float4 q1 = s.refs[3 * r + 1], q2 = s.refs[3 * r + 2];
+                t = moller_trumbore<WGSL>(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z));
+                if (t > 0.0f && t < closest) {
+                    closest = t;
+                    best_id = id;
+                    best_ref = r;
+                    hit = true;
+                    if (ANY) {
+                        out = HitRec{closest, best_id, best_ref};
+                        return true;
+                    }
+                }
+            }
+        }
+        if (hit && closest < fminf(fminf(t_max.x, t_max.y), t_max.z)) break;
+
+        if (t_max.x < t_max.y && t_max.x < t_max.z) {
+            int nx = (int)cx + sx;
+            if (nx < 0 || nx >= (int)s.gx) break;
+            cx = (uint32_t)nx;
+            t_max.x += t_delta.x;
+        } else if (t_max.y < t_max.z) {
+            int ny = (int)cy + sy;
+            if (ny < 0 || ny >= (int)s.gy) break;
+            cy = (uint32_t)ny;
+            t_max.y += t_delta.y;
+        } else {
+            int nz = (int)cz + sz;
+            if (nz < 0 || nz >= (int)s.gz) break;
+            cz = (uint32_t)nz;
+            t_max.z += t_delta.z;
+        }
+    }
+    out = HitRec{closest, best_id, best_ref};
+    return hit;
+}
+
+// Geometric normal of a hit (triangle: normalize(e1 x e2), :277; box: axis of largest |p|-half, :218-227).
+__device__ inline V3 hit_normal(const DevScene& s, const HitRec& h, V3 pos) {
+    if (h.ref != MISS) {
+        const float4 q1 = s.refs[3 * h.ref + 1], q2 = s.refs[3 * h.ref + 2];
+        return normalize(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));
+    }
+    const float4 c = s.box_frame[4 * h.id + 2], hf = s.box_frame[4 * h.id + 3];
+    V3 p = pos - v3(c.x, c.y, c.z);
+    V3 dd = vabs(p) - v3(hf.x, hf.y, hf.z);
+    if (dd.x > dd.y && dd.x > dd.z) return v3(sign0(p.x), 0.0f, 0.0f);
+    if (dd.y > dd.z) return v3(0.0f, sign0(p.y), 0.0f);
+    return v3(0.0f, 0.0f, sign0(p.z));
+}
+
+// Primary ray direction for a pixel (:634-649).
+__device__ inline V3 primary_dir(const DevFrame& f, uint32_t px, uint32_t py) {
+    float u = ((float)px + 0.5f) / (float)f.width;
+    float v = ((float)py + 0.5f) / (float)f.height;
+    float ndc_x = u * 2.0f - 1.0f;
+    float ndc_y = v * 2.0f - 1.0f;
+    float aspect = (float)f.width / (float)f.height;
+    V3 a = v3(f.fwd[0], f.fwd[1], f.fwd[2]);
+    V3 b = ((v3(f.right[0], f.right[1], f.right[2]) * ndc_x) * aspect) * f.fov_scale;
+    V3 c = (v3(f.up[0], f.up[1], f.up[2]) * (-ndc_y)) * f.fov_scale;
+    return normalize((a + b) + c);
+}
+
+// Wave-level sum of per-lane counters, one atomic per wave per counter.
+__device__ inline void flush_stats(unsigned long long* stats, unsigned long long rays, unsigned long long phits,
+                                   unsigned long long srays, unsigned long long shits, const Counters& c) {
+    unsigned long long v[7] = {rays, phits, srays, shits, c.cells, c.tri, c.box};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[k], x);
+    }
+}
+
+// Blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of logical blocks
+// so neighbouring image regions - which walk the same grid cells - meet in one L2.
+__device__ inline uint32_t xcd_remap(uint32_t b, uint32_t nblocks) {
+    const uint32_t q = nblocks / 8, r = nblocks % 8, xcd = b % 8;
+    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + b / 8;
+}
+
+// One lane per pixel, one wave per 8x8 pixel block, four waves per workgroup.
+template <bool WGSL, bool SHADOW, bool STATS>
+__global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
+                                                       uint2* __restrict__ out_s, unsigned long long* stats) {
+    const uint32_t block = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t wave = block * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t sub_per_tile = m.sub_x * m.sub_y;
+    if (wave >= m.n_local * sub_per_tile) return;
+    const uint32_t lt = wave / sub_per_tile, sub = wave % sub_per_tile;
+    const uint32_t lx = (sub % m.sub_x) * 8 + (lane & 7), ly = (sub / m.sub_x) * 8 + (lane >> 3);
+    const uint32_t tile = m.first + lt * m.stride;
+    const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
+    const bool in_tile = lx < m.tile_w && ly < m.tile_h;
+    const bool live = in_tile && px < f.width && py < f.height;
+
+    uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
+    Counters ctr{0, 0, 0, 0};
+    unsigned long long n_rays = 0, n_ph = 0, n_sr = 0, n_sh = 0;
+    if (live) {
+        const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+        const V3 d = primary_dir(f, px, py);
+        HitRec h;
+        n_rays++;
+        if (trace_ray<WGSL, false, STATS>(s, o, d, h, ctr)) {
+            n_ph++;
+            ph = make_uint2(h.id, __float_as_uint(h.t));
+            if (SHADOW) {
+                const V3 pos = o + d * h.t;
+                V3 n = hit_normal(s, h, pos);
+                if (dot(n, d) > 0.0f) n = neg(n);
+                const V3 so = pos + n * f.shadow_offset;
+                const V3 sd = v3(f.shadow_dir[0], f.shadow_dir[1], f.shadow_dir[2]);
+                HitRec oh;
+                n_rays++;
+                n_sr++;
+                if (trace_ray<WGSL, true, STATS>(s, so, sd, oh, ctr)) {
+                    n_sh++;
+                    sh = make_uint2(oh.id, __float_as_uint(oh.t));
+                }
+            }
+        }
+    }
+    if (in_tile) {
+        const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
+        out_p[oi] = ph;
+        if (SHADOW) out_s[oi] = sh;
+    }
+    if (STATS) flush_stats(stats, n_rays, n_ph, n_sr, n_sh, ctr);
+}
+
+// Explicit ray list: one lane per ray.
+template <bool WGSL, bool ANY, bool STATS>
+__global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __restrict__ origins,
+                                                    const float* __restrict__ dirs, uint32_t n,
+                                                    uint2* __restrict__ out, unsigned long long* stats) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Counters ctr{0, 0, 0, 0};
+    unsigned long long n_rays = 0, n_hit = 0;
+    if (i < n) {
+        HitRec h;
+        n_rays = 1;
+        bool hit = trace_ray<WGSL, ANY, STATS>(s, ld3(origins + 3 * (size_t)i), ld3(dirs + 3 * (size_t)i), h, ctr);
+        n_hit = hit ? 1 : 0;
+        out[i] = hit ? make_uint2(h.id, __float_as_uint(h.t)) : make_uint2(MISS, 0u);
+    }
+    if (STATS) flush_stats(stats, n_rays, n_hit, 0, 0, ctr);
+}
+
+// One pixel, one lane: what the shader writes for its debug pixel (:695-709), geometry fields.
+template <bool WGSL>
+__global__ void k_debug_pixel(DevScene s, DevFrame f, uint32_t px, uint32_t py, float* __restrict__ info20) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+    const V3 d = primary_dir(f, px, py);
+    HitRec h;
+    Counters ctr{0, 0, 0, 0};
+    const bool hit = trace_ray<WGSL, false, false>(s, o, d, h, ctr);
+    for (int k = 0; k < 20; ++k) info20[k] = 0.0f;
+    info20[0] = o.x, info20[1] = o.y, info20[2] = o.z;
+    info20[3] = hit ? 1.0f : 0.0f;
+    info20[4] = d.x, info20[5] = d.y, info20[6] = d.z;
+    info20[7] = hit ? h.t : 1e10f;
+    info20[11] = hit ? (float)h.id : -1.0f;
+    info20[15] = (float)ctr.steps;
+    if (hit) {
+        const V3 pos = o + d * h.t;
+        const V3 n = hit_normal(s, h, pos);
+        info20[8] = pos.x, info20[9] = pos.y, info20[10] = pos.z;
+        info20[12] = n.x, info20[13] = n.y, info20[14] = n.z;
+    }
+}
+
+}  // namespace rt

@@ -1,0 +1,273 @@
+"""Host side of the trace core, shaped after the reference's own call sites.
+
+  Camera        src/camera.rs:43-122         yaw/pitch camera, per-scene start poses, to_uniform
+  TraceCore     include/rt_mi355.h           thin object wrapper over the C ABI (one rt_ctx)
+  RayTracer     src/renderer.rs:40-351,800+  "new(scene) builds the grid, render(camera, time) traces"
+                src/core/ray_tracing_layer.rs:155,436  (ComputeState::new / ::render)
+
+Nothing here computes an intersection: arrays go to librt_mi355.so, hit records come back.
+Outputs may be numpy arrays (host, synchronous) or torch CUDA tensors / raw device pointers
+(asynchronous on the context's stream).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import (BOX_DTYPE, HIT_DTYPE, RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES, RT_MISS, TRIANGLE_DTYPE,
+                   CameraUniform, GridMetadata, RayDebugInfo, RtParams, RtShard, RtStats)
+
+DEFAULT_FOV = 0.785398  # raytracer_unified.wgsl:4, src/renderer.rs DEFAULT_FOV
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt error {code}: {msg}")
+        self.code = code
+
+
+def default_params(**overrides):
+    p = RtParams()
+    _lib.load().rt_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if k == "light_direction":
+            p.light_direction = (C.c_float * 3)(*v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+class Camera:
+    """reference: src/camera.rs:43-122 (movement/keyboard handling is not part of the trace path)."""
+
+    # src/camera.rs:59-66
+    SCENE_POSES = {
+        "composed": ((0.0, 40.0, 40.0), math.pi, -0.7),
+        "walls": ((0.0, 5.0, 0.0), 0.0, 0.0),
+        "tunnel": ((0.0, 0.0, 20.0), math.pi, 0.0),
+        "gltf": ((200.0, 200.0, 300.0), 3.35, -0.28),
+        "pyramid": ((0.0, 8.0, 20.0), math.pi, -0.5),
+    }
+    DEFAULT_POSE = ((0.0, 8.0, 15.0), math.pi, -0.6)
+
+    def __init__(self, position, yaw, pitch):
+        self.position = tuple(float(x) for x in position)
+        self.yaw, self.pitch = float(yaw), float(pitch)
+
+    @classmethod
+    def for_scene(cls, scene_name):
+        return cls(*cls.SCENE_POSES.get(scene_name, cls.DEFAULT_POSE))
+
+    def to_uniform(self, time=0.0, screen_height=1080.0, fov=DEFAULT_FOV, show_grid=False):
+        out = CameraUniform()
+        _lib.load().rt_camera_to_uniform((C.c_float * 3)(*self.position), self.yaw, self.pitch, time, screen_height, fov,
+                                         int(show_grid), C.byref(out))
+        return out
+
+    def forward(self):
+        return tuple(self.to_uniform().forward)
+
+    def right(self):
+        return tuple(self.to_uniform().right)
+
+    def up(self):
+        return (0.0, 1.0, 0.0)
+
+
+def _ptr(a):
+    """host numpy array, torch tensor, int device pointer or None -> c_void_p."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return C.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):
+        if not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+def shard_pixels(width, height, shard):
+    """Number of rt_hit records a trace call with this shard writes."""
+    if shard is None:
+        return width * height
+    tiles_x = -(-width // shard.tile_w)
+    tiles_y = -(-height // shard.tile_h)
+    n_tiles = tiles_x * tiles_y
+    n_local = -(-(n_tiles - shard.first) // shard.stride) if shard.first < n_tiles else 0
+    return n_local * shard.tile_w * shard.tile_h
+
+
+class TraceCore:
+    """One rt_ctx. Methods are the C ABI's entry points with numpy/torch conveniences."""
+
+    def __init__(self, device_id=0, params=None):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        self.params = params if params is not None else default_params()
+        rc = self._L.rt_create(C.byref(self._h), device_id, C.byref(self.params))
+        if rc != 0:
+            raise RtError(rc, self._L.rt_create_error().decode())
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RtError(rc, self._L.rt_last_error(self._h).decode())
+
+    # ---- streams / timing
+    def set_stream(self, stream_ptr):
+        self._ck(self._L.rt_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        self._ck(self._L.rt_sync(self._h))
+
+    def timer_begin(self):
+        self._ck(self._L.rt_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        self._ck(self._L.rt_timer_end(self._h, C.byref(ms)))
+        return ms.value
+
+    # ---- scene / grid
+    def set_scene(self, boxes=None, tris=None):
+        boxes = np.ascontiguousarray(boxes if boxes is not None else np.zeros(0, BOX_DTYPE), BOX_DTYPE)
+        tris = np.ascontiguousarray(tris if tris is not None else np.zeros(0, TRIANGLE_DTYPE), TRIANGLE_DTYPE)
+        self._ck(self._L.rt_set_scene(self._h, _ptr(boxes), len(boxes), _ptr(tris), len(tris)))
+        self.nb, self.nt = len(boxes), len(tris)
+
+    def set_grid_csr(self, meta, cell_start, indices):
+        cell_start = np.ascontiguousarray(cell_start, np.uint32)
+        indices = np.ascontiguousarray(indices, np.uint32)
+        self._ck(self._L.rt_set_grid_csr(self._h, C.byref(meta), _ptr(cell_start), _ptr(indices)))
+
+    def set_grid_dense(self, meta, dense_bytes, tri_cells=False):
+        dense_bytes = np.ascontiguousarray(dense_bytes, np.uint8)
+        rec = 1040 if tri_cells else 32784
+        if dense_bytes.size % rec:
+            raise ValueError("dense grid bytes are not a whole number of cell records")
+        fn = self._L.rt_set_grid_dense_tri if tri_cells else self._L.rt_set_grid_dense
+        self._ck(fn(self._h, C.byref(meta), _ptr(dense_bytes), dense_bytes.size // rec))
+
+    def build_grid(self, cell_size=0.0, max_per_cell=0, mode=RT_GRID_HIERARCHICAL):
+        self._ck(self._L.rt_build_grid(self._h, cell_size, max_per_cell, mode))
+        return self.grid_info()
+
+    def grid_info(self):
+        meta, nc, nr = GridMetadata(), C.c_uint32(), C.c_uint32()
+        self._ck(self._L.rt_get_grid(self._h, C.byref(meta), C.byref(nc), C.byref(nr)))
+        return meta, nc.value, nr.value
+
+    def read_grid_csr(self):
+        _, nc, nr = self.grid_info()
+        cell_start, indices = np.empty(nc + 1, np.uint32), np.empty(nr, np.uint32)
+        self._ck(self._L.rt_read_grid_csr(self._h, _ptr(cell_start), _ptr(indices)))
+        return cell_start, indices
+
+    def update_vertices(self, xyz9, first=0, count=None):
+        if isinstance(xyz9, np.ndarray):
+            xyz9 = np.ascontiguousarray(xyz9, np.float32)
+            n = xyz9.size // 9
+        else:
+            n = xyz9.numel() // 9
+        self._ck(self._L.rt_update_vertices(self._h, _ptr(xyz9), first, n if count is None else count))
+
+    # ---- tracing
+    def trace_primary(self, cam, width, height, shard=None, shadow=True, out_primary=None, out_shadow=None):
+        """Returns (primary, shadow|None). Pass torch CUDA tensors (n,2 int32/8 bytes per record) or
+        device pointers as out_* to keep results on the GPU; default is new numpy HIT_DTYPE arrays."""
+        n = shard_pixels(width, height, shard)
+        if out_primary is None:
+            out_primary = np.empty(n, HIT_DTYPE)
+        if shadow and out_shadow is None:
+            out_shadow = np.empty(n, HIT_DTYPE)
+        self._ck(self._L.rt_trace_primary(self._h, C.byref(cam), width, height,
+                                          C.byref(shard) if shard is not None else None, _ptr(out_primary),
+                                          _ptr(out_shadow) if shadow else None))
+        return out_primary, (out_shadow if shadow else None)
+
+    def trace_rays(self, origins, dirs, cam=None, any_hit=False, out=None, n=None):
+        if isinstance(origins, np.ndarray):
+            origins = np.ascontiguousarray(origins, np.float32)
+            dirs = np.ascontiguousarray(dirs, np.float32)
+            n = origins.size // 3
+        elif n is None:
+            n = origins.numel() // 3
+        if out is None:
+            out = np.empty(n, HIT_DTYPE)
+        self._ck(self._L.rt_trace_rays(self._h, C.byref(cam) if cam is not None else None, _ptr(origins), _ptr(dirs), n,
+                                       _ptr(out), int(any_hit)))
+        return out
+
+    def assemble_tiles(self, gathered, width, height, tile_w, tile_h, n_ranks, image):
+        self._ck(self._L.rt_assemble_tiles(self._h, _ptr(gathered), width, height, tile_w, tile_h, n_ranks, _ptr(image)))
+
+    def debug_pixel(self, cam, width, height, px, py):
+        info = RayDebugInfo()
+        self._ck(self._L.rt_debug_pixel(self._h, C.byref(cam), width, height, px, py, C.byref(info)))
+        return info
+
+    def set_collect_stats(self, enabled):
+        self._ck(self._L.rt_set_collect_stats(self._h, int(enabled)))
+
+    def stats(self):
+        s = RtStats()
+        self._ck(self._L.rt_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    # ---- primitive routines
+    def intersect_aabb_pairs(self, origins, dirs, box_min, box_max):
+        origins, dirs, box_min, box_max = (np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+                                           for a in (origins, dirs, box_min, box_max))
+        out = np.empty((len(origins), len(box_min)), np.float32)
+        self._ck(self._L.rt_intersect_aabb_pairs(self._h, _ptr(origins), _ptr(dirs), len(origins), _ptr(box_min),
+                                                 _ptr(box_max), len(box_min), _ptr(out)))
+        return out
+
+    def intersect_tri_pairs(self, origins, dirs, v012):
+        origins, dirs = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (origins, dirs))
+        v012 = np.ascontiguousarray(v012, np.float32).reshape(-1, 9)
+        out = np.empty((len(origins), len(v012)), np.float32)
+        self._ck(self._L.rt_intersect_tri_pairs(self._h, _ptr(origins), _ptr(dirs), len(origins), _ptr(v012), len(v012),
+                                                _ptr(out)))
+        return out
+
+
+def triangles_from_xyz9(xyz9, material_id=0):
+    """(n,9) float32 vertex rows -> TriangleData records (src/types.rs:211-233 with zero uvs)."""
+    xyz9 = np.ascontiguousarray(xyz9, np.float32).reshape(-1, 9)
+    t = np.zeros(len(xyz9), TRIANGLE_DTYPE)
+    t["v0"], t["v1"], t["v2"] = xyz9[:, 0:3], xyz9[:, 3:6], xyz9[:, 6:9]
+    t["material_id"] = material_id
+    return t
+
+
+class RayTracer:
+    """The renderer-shaped wrapper: construct with a scene (grid is built on the GPU, as
+    RayTracer::new calls HierarchicalGrid::build, src/renderer.rs:97-99), then render() per frame
+    (src/renderer.rs:800-868). Returns hit records instead of an RGBA texture: shading is outside
+    the trace core."""
+
+    def __init__(self, boxes=None, tris=None, width=1920, height=1080, device_id=0, params=None):
+        self.width, self.height = width, height
+        self.core = TraceCore(device_id, params)
+        self.core.set_scene(boxes, tris)
+        self.grid_meta, self.n_cells, self.n_refs = self.core.build_grid()
+
+    def render(self, camera, time=0.0, shadow=True, **kw):
+        cam = camera.to_uniform(time, float(self.height), self.core.params.fov, False)
+        return self.core.trace_primary(cam, self.width, self.height, shadow=shadow, **kw)

@@ -115,6 +115,13 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C ray-tracer_amd/csrc` "
                 "(or __graft_entry__.build()). There is no CPU fallback for the trace core.")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 (same soname as /opt/rocm's). If it is
+        # loaded first, this library binds to that copy; loaded the other way round the process would hold two
+        # runtimes and the second one finds no device. Plain C/C++/Rust callers simply use /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError here = header and library disagree

@@ -75,6 +75,18 @@ class Camera:
         return (0.0, 1.0, 0.0)
 
 
+def _ref(x, ctype):
+    """byref(x) for a ctypes struct of type `ctype`, or of any other struct type with the same layout size
+    (callers may hold their own declaration of the wire structs)."""
+    if x is None:
+        return None
+    if isinstance(x, ctype):
+        return C.byref(x)
+    if isinstance(x, C.Structure) and C.sizeof(x) == C.sizeof(ctype):
+        return C.cast(C.byref(x), C.POINTER(ctype))
+    raise TypeError(f"expected {ctype.__name__}, got {type(x).__name__}")
+
+
 def _ptr(a):
     """host numpy array, torch tensor, int device pointer or None -> c_void_p."""
     if a is None:
@@ -153,7 +165,7 @@ class TraceCore:
     def set_grid_csr(self, meta, cell_start, indices):
         cell_start = np.ascontiguousarray(cell_start, np.uint32)
         indices = np.ascontiguousarray(indices, np.uint32)
-        self._ck(self._L.rt_set_grid_csr(self._h, C.byref(meta), _ptr(cell_start), _ptr(indices)))
+        self._ck(self._L.rt_set_grid_csr(self._h, _ref(meta, GridMetadata), _ptr(cell_start), _ptr(indices)))
 
     def set_grid_dense(self, meta, dense_bytes, tri_cells=False):
         dense_bytes = np.ascontiguousarray(dense_bytes, np.uint8)
@@ -161,7 +173,7 @@ class TraceCore:
         if dense_bytes.size % rec:
             raise ValueError("dense grid bytes are not a whole number of cell records")
         fn = self._L.rt_set_grid_dense_tri if tri_cells else self._L.rt_set_grid_dense
-        self._ck(fn(self._h, C.byref(meta), _ptr(dense_bytes), dense_bytes.size // rec))
+        self._ck(fn(self._h, _ref(meta, GridMetadata), _ptr(dense_bytes), dense_bytes.size // rec))
 
     def build_grid(self, cell_size=0.0, max_per_cell=0, mode=RT_GRID_HIERARCHICAL):
         self._ck(self._L.rt_build_grid(self._h, cell_size, max_per_cell, mode))
@@ -195,8 +207,8 @@ class TraceCore:
             out_primary = np.empty(n, HIT_DTYPE)
         if shadow and out_shadow is None:
             out_shadow = np.empty(n, HIT_DTYPE)
-        self._ck(self._L.rt_trace_primary(self._h, C.byref(cam), width, height,
-                                          C.byref(shard) if shard is not None else None, _ptr(out_primary),
+        self._ck(self._L.rt_trace_primary(self._h, _ref(cam, CameraUniform), width, height, _ref(shard, RtShard),
+                                          _ptr(out_primary),
                                           _ptr(out_shadow) if shadow else None))
         return out_primary, (out_shadow if shadow else None)
 
@@ -209,7 +221,7 @@ class TraceCore:
             n = origins.numel() // 3
         if out is None:
             out = np.empty(n, HIT_DTYPE)
-        self._ck(self._L.rt_trace_rays(self._h, C.byref(cam) if cam is not None else None, _ptr(origins), _ptr(dirs), n,
+        self._ck(self._L.rt_trace_rays(self._h, _ref(cam, CameraUniform), _ptr(origins), _ptr(dirs), n,
                                        _ptr(out), int(any_hit)))
         return out
 
@@ -218,7 +230,7 @@ class TraceCore:
 
     def debug_pixel(self, cam, width, height, px, py):
         info = RayDebugInfo()
-        self._ck(self._L.rt_debug_pixel(self._h, C.byref(cam), width, height, px, py, C.byref(info)))
+        self._ck(self._L.rt_debug_pixel(self._h, _ref(cam, CameraUniform), width, height, px, py, C.byref(info)))
         return info
 
     def set_collect_stats(self, enabled):

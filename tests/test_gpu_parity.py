@@ -1,0 +1,483 @@
+"""Parity of the HIP path with the CPU oracle, through the C ABI (ctypes -> librt_mi355.so).
+
+Bar: bit-exact. Object ids must be equal and hit distances must have identical f32 bit patterns
+(the kernels evaluate the reference's expression trees with contraction off and correctly rounded
+divide/sqrt), so no tolerance is written anywhere in this file. All tests need a real MI355X."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_hits_equal(got, want, what=""):
+    bad = np.flatnonzero(got["id"] != want["id"])
+    assert bad.size == 0, f"{what}: {bad.size} ids differ, first at {bad[:5]}: {got[bad[:5]]} vs {want[bad[:5]]}"
+    bad = np.flatnonzero(bits(got["t"]) != bits(want["t"]))
+    assert bad.size == 0, f"{what}: {bad.size} t values differ, first at {bad[:5]}: {got[bad[:5]]} vs {want[bad[:5]]}"
+
+
+def oparams(ob, p):
+    return ob.Params.default(**{k: getattr(p, k) for k in ("finest_cell_size", "max_objects_per_cell", "max_dda_steps",
+                                                           "wgsl_compat", "lod_cull", "moving_box_count", "fov",
+                                                           "shadow_offset")})
+
+
+def ocam(ob, cam):
+    o = ob.CameraUniform()
+    C.memmove(C.byref(o), C.byref(cam), C.sizeof(o))
+    return o
+
+
+def setup_scene(core, ob, boxes, tris, **grid_kw):
+    """Uploads the scene, bins it on the GPU, checks the grid against the oracle's and returns the oracle scene."""
+    core.set_scene(boxes, tris)
+    meta, n_cells, n_refs = core.build_grid(cell_size=grid_kw.get("cell_size", 0.0),
+                                            max_per_cell=grid_kw.get("max_per_cell", 0), mode=grid_kw.get("mode", 0))
+    scene = ob.Scene(boxes, tris, **grid_kw)
+    assert bytes(meta)[:32] == bytes(scene.grid.meta)[:32], "bounds / cell size differ"
+    assert meta.fine_dims == scene.grid.meta.fine_dims
+    cs, idx = core.read_grid_csr()
+    assert n_cells == scene.grid.n_cells and n_refs == scene.grid.n_refs
+    assert np.array_equal(cs, scene.grid.cell_start) and np.array_equal(idx, scene.grid.indices)
+    return scene
+
+
+def random_boxes(ob, n, seed, extent=40.0, moving_last=0):
+    rng = np.random.default_rng(seed)
+    boxes = np.zeros(n, ob.BOX_DTYPE)
+    for i in range(n):
+        c = rng.uniform(-extent, extent, 3).astype(np.float32)
+        h = rng.uniform(0.5, 6.0, 3).astype(np.float32)
+        if i >= n - moving_last:  # BoxData::create_moving_box, src/types.rs:123-151
+            c1 = (c + rng.uniform(-10, 10, 3)).astype(np.float32)
+            lo = np.minimum(c - h, c1 - h) - np.float32(0.5)
+            hi = np.maximum(c + h, c1 + h) + np.float32(0.5)
+            boxes[i] = ob.make_box(lo, hi, center0=c, center1=c1, half=h)
+        else:
+            boxes[i] = ob.make_box(c - h, c + h)
+        boxes[i]["reflectivity"] = 0.0
+    return boxes
+
+
+# ------------------------------------------------------------------------------ primitive routines
+
+def special_rays():
+    o = [(0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 2, 3), (0.5, 0.25, -7), (0, 0, 0), (0, 0, 0), (3, 3, 3)]
+    d = [(0, 0, -1), (1, 0, 0), (0, -0.0, 1), (-0.0, 0, -1), (0, 1e-9, -1), (1e-9, -1e-9, -1), (0.6, 0, -0.8),
+         (-0.57735026, -0.57735026, -0.57735026)]
+    return np.array(o, np.float32), np.array(d, np.float32)
+
+
+@pytest.mark.parametrize("wgsl", [0, 1])
+@pytest.mark.parametrize("count", [100, 1000, 10000])
+def test_aabb_pairs_criterion_particle_scene(rt, ob, count, wgsl):
+    """benches/bounding_volumes.rs:147-179: 100 rays x {100, 1000, 10000} boxes; plus axis-aligned and
+    signed-zero directions for the safe-inverse branch (src/math/ray.rs:8-12 / wgsl:162-166)."""
+    core = rt.TraceCore(0, rt.default_params(wgsl_compat=wgsl))
+    mn, mx = ob.particle_aabbs(count, 0.5)
+    d = np.stack([ob.random_unit_vector(i) for i in range(100)])
+    o = np.zeros_like(d)
+    so, sd = special_rays()
+    o, d = np.concatenate([o, so]), np.concatenate([d, sd])
+    got = core.intersect_aabb_pairs(o, d, mn, mx)
+    want = ob.intersect_aabb_pairs(o, d, mn, mx, wgsl)
+    assert np.array_equal(bits(got), bits(want))
+    assert (want[:100] > 0).sum() == (got[:100] > 0).sum() > 0  # the benchmark's hit_count
+    core.close()
+
+
+@pytest.mark.parametrize("wgsl", [0, 1])
+def test_tri_pairs(rt, ob, car_xyz9, wgsl):
+    core = rt.TraceCore(0, rt.default_params(wgsl_compat=wgsl))
+    o, d = ob.generate_test_rays(200)
+    tri = ob.generate_test_triangles(2000)
+    v = np.concatenate([tri["v0"], tri["v1"], tri["v2"]], axis=1)
+    got, want = core.intersect_tri_pairs(o, d, v), ob.intersect_tri_pairs(o, d, v, wgsl)
+    assert np.array_equal(bits(got), bits(want)) and (want > 0).sum() > 10
+    cam = ob.camera_to_uniform((200, 200, 300), 3.35, -0.28, 0.0, 16.0)
+    o, d = ob.primary_rays(cam, 24, 16)
+    got, want = core.intersect_tri_pairs(o, d, car_xyz9), ob.intersect_tri_pairs(o, d, car_xyz9, wgsl)
+    assert np.array_equal(bits(got), bits(want)) and (want > 0).sum() > 100
+    core.close()
+
+
+def test_reference_known_answers_on_gpu(core):
+    """src/math/ray.rs:43-71 and src/core/triangle_intersection.rs:219-252,357-364 evaluated by the kernels."""
+    t = core.intersect_aabb_pairs([(0, 0, 0), (0, 0, 0), (5, 0, 0)], [(1, 0, 0)] * 3,
+                                  [(5, -1, -1), (5, 2, 2), (0, -1, -1)], [(10, 1, 1), (10, 3, 3), (10, 1, 1)])
+    assert t[0, 0] == 5.0 and t[1, 1] == -1.0 and t[2, 2] == 5.0
+    tri = [(-1, 0, -5, 1, 0, -5, 0, 1, -5)]
+    d_miss = np.array([5, 0, -1], np.float32) * np.float32(1 / math.sqrt(26))
+    t = core.intersect_tri_pairs([(0, 0, 0), (0, 0, 0), (0, 0, 0), (0, 0, -5)], [(0, 0, -1), d_miss, (0, 0, 1), (1, 0, 0)], tri)
+    assert t[0, 0] == 5.0 and t[1, 0] == -1.0 and t[2, 0] == -1.0 and t[3, 0] == -1.0
+
+
+# ------------------------------------------------------------------------------ grid binning
+
+def test_grid_build_models(core, ob, car_xyz9, phoenix_xyz9, golden):
+    for name, xyz in (("car", car_xyz9), ("phoenix", phoenix_xyz9)):
+        setup_scene(core, ob, None, ob.triangles_from_xyz9(xyz))
+        cs, idx = core.read_grid_csr()
+        assert np.array_equal(cs, golden[f"{name}_cell_start"]) and np.array_equal(idx, golden[f"{name}_indices"])
+
+
+@pytest.mark.parametrize("cell_size", [16.0, 5.0, 1.0])
+def test_grid_build_pyramid(core, ob, cell_size):
+    setup_scene(core, ob, None, ob.pyramid_triangles(), cell_size=cell_size)
+
+
+def test_grid_build_boxes_and_triangles(core, ob):
+    setup_scene(core, ob, random_boxes(ob, 300, 1, moving_last=3), ob.generate_test_triangles(5000), cell_size=8.0)
+    setup_scene(core, ob, random_boxes(ob, 17, 2), None)
+
+
+def test_grid_build_cap_drops_highest_ids(core, ob):
+    """src/grid.rs:92-100 with a small cap: the lowest ids of every over-full cell survive."""
+    tris = ob.generate_test_triangles(20000)
+    scene = setup_scene(core, ob, None, tris, max_per_cell=16)
+    assert scene.grid.dropped > 0
+    setup_scene(core, ob, None, tris[:9000], max_per_cell=8192)  # reference cap, nothing dropped
+
+
+def test_grid_build_triangle_grid_mode(core, ob, car_xyz9):
+    """src/grid_triangles.rs:29-213: cap 256, dims clamped to [1,1024], i32 cell coordinates."""
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    setup_scene(core, ob, None, tris, mode=ob.GRID_TRIANGLES)
+    setup_scene(core, ob, None, ob.generate_test_triangles(40000), mode=ob.GRID_TRIANGLES)  # cap 256 bites
+    setup_scene(core, ob, None, tris[:50], cell_size=0.3, mode=ob.GRID_TRIANGLES, max_per_cell=8)  # dims hit 1024
+
+
+def test_grid_build_empty_scene(core, ob):
+    setup_scene(core, ob, None, None)
+    setup_scene(core, ob, None, None, mode=ob.GRID_TRIANGLES)
+    cam = ob.camera_to_uniform((0, 0, 10), math.pi, 0.0, 0.0, 8.0)
+    p, s = core.trace_primary(cam, 16, 8)
+    assert np.all(p["id"] == ob.MISS) and np.all(s["id"] == ob.MISS)
+
+
+def test_grid_rebuild_after_vertex_update(core, ob, phoenix_xyz9):
+    """The animated path: new vertices every frame, rebuild on the GPU, same answer as a fresh CPU build."""
+    core.set_scene(None, ob.triangles_from_xyz9(phoenix_xyz9))
+    core.build_grid()
+    centre = phoenix_xyz9.reshape(-1, 3).mean(axis=0).astype(np.float32)
+    for frame in (7, 45):
+        a = np.float32(2 * math.pi * frame / 120)
+        ca, sa = np.float32(math.cos(a)), np.float32(math.sin(a))
+        v = phoenix_xyz9.reshape(-1, 3) - centre
+        moved = np.stack([v[:, 0] * ca + v[:, 2] * sa, v[:, 1], -v[:, 0] * sa + v[:, 2] * ca], axis=1) + centre
+        moved[:, 1] += np.float32(10 * (math.sin(2 * frame / 60) + 1) / 2)
+        moved = moved.astype(np.float32).reshape(-1, 9)
+        core.update_vertices(moved)
+        with pytest.raises(Exception):
+            core.trace_primary(ob.camera_to_uniform((0, 0, 0), 0, 0), 8, 8)  # stale grid must be refused
+        meta, nc, nr = core.build_grid()
+        scene = ob.Scene(None, ob.triangles_from_xyz9(moved))
+        cs, idx = core.read_grid_csr()
+        assert meta.fine_dims == scene.grid.meta.fine_dims and bytes(meta)[:32] == bytes(scene.grid.meta)[:32]
+        assert np.array_equal(cs, scene.grid.cell_start) and np.array_equal(idx, scene.grid.indices)
+        cam = ob.camera_to_uniform((-300, 250, 600), 2.7, -0.2, 0.0, 90.0)
+        p, s = core.trace_primary(cam, 160, 90)
+        op, os_, _ = ob.trace_primary(scene, cam, 160, 90)
+        assert_hits_equal(p, op, "animated primary")
+        assert_hits_equal(s, os_, "animated shadow")
+        assert (op["id"] != ob.MISS).sum() > 200
+
+
+# ------------------------------------------------------------------------------ primary + shadow trace
+
+def check_frame(core, ob, scene, cam, w, h, shard=None, what=""):
+    p, s = core.trace_primary(cam, w, h, shard=shard)
+    oshard = ob.Shard(shard.tile_w, shard.tile_h, shard.first, shard.stride) if shard is not None else None
+    op, os_, st = ob.trace_primary(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params), shard=oshard)
+    assert_hits_equal(p, op, what + " primary")
+    assert_hits_equal(s, os_, what + " shadow")
+    return op, os_, st
+
+
+def test_trace_matches_committed_golden(core, ob, rt, golden, car_xyz9):
+    cam = rt.Camera.for_scene("pyramid").to_uniform(0.0, 36.0)
+    for name, cell in (("pyramid", 16.0), ("pyramid_c1", 1.0)):
+        core.set_scene(None, ob.pyramid_triangles())
+        core.build_grid(cell_size=cell)
+        p, s = core.trace_primary(cam, 64, 36)
+        assert_hits_equal(p, golden[f"{name}_primary"], name)
+        assert_hits_equal(s, golden[f"{name}_shadow"], name)
+    core.set_scene(None, rt.triangles_from_xyz9(car_xyz9))
+    core.build_grid()
+    p, s = core.trace_primary(rt.Camera.for_scene("gltf").to_uniform(0.0, 36.0), 64, 36)
+    assert_hits_equal(p, golden["car_primary"], "car")
+    assert_hits_equal(s, golden["car_shadow"], "car")
+
+
+@pytest.mark.parametrize("w,h", [(64, 36), (333, 187), (1920, 1080)])
+def test_trace_car(core, ob, rt, car_xyz9, w, h):
+    """BASELINE config 2: the bundled static model from the `SCENE=gltf` start pose (src/camera.rs:63)."""
+    scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+    op, os_, st = check_frame(core, ob, scene, cam, w, h, what=f"car {w}x{h}")
+    assert st["primary_hits"] > 0.3 * w * h and st["shadow_hits"] > 0
+
+
+def test_trace_car_other_views(core, ob, rt, car_xyz9):
+    scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))
+    views = [((0, 100, 0), 0.3, -1.2), ((-400, 50, -500), 0.7, 0.0), ((0, 150, 50), 1.0, -0.4),  # inside the grid
+             ((2000, 900, 2500), 3.8, -0.3), ((0, -200, 0), 0.0, 1.3), ((0, 50, 3000), 0.0, 0.0)]  # last one looks away
+    for pos, yaw, pitch in views:
+        cam = rt.Camera(pos, yaw, pitch).to_uniform(0.0, 120.0)
+        check_frame(core, ob, scene, cam, 200, 120, what=f"car from {pos}")
+
+
+def test_trace_finer_grids(core, ob, rt, car_xyz9):
+    """Tuned cell sizes (not the reference's 16.0): long traversals, the 200-step cap bites at 2.0."""
+    for cell in (8.0, 2.0):
+        scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9), cell_size=cell)
+        cam = rt.Camera.for_scene("gltf").to_uniform(0.0, 90.0)
+        check_frame(core, ob, scene, cam, 160, 90, what=f"car cell {cell}")
+
+
+def test_trace_phoenix(core, ob, rt, phoenix_xyz9):
+    scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(phoenix_xyz9))
+    cam = rt.Camera((-300, 250, 600), 2.7, -0.2).to_uniform(0.0, 180.0)
+    _, _, st = check_frame(core, ob, scene, cam, 320, 180, what="phoenix")
+    assert st["primary_hits"] > 1000
+
+
+def test_trace_massive_benchmark_scene_ties(core, ob, rt):
+    """BASELINE config 3's scene (src/core/benchmark.rs:99-123): positions repeat with period 10000, so with
+    30000 triangles every hit is an exact three-way tie; list order must pick the same id as the oracle."""
+    tris = ob.generate_test_triangles(30000)
+    scene = setup_scene(core, ob, None, tris)
+    cam = rt.Camera((0, 0, 150), math.pi, 0.0).to_uniform(0.0, 54.0)
+    op, _, st = check_frame(core, ob, scene, cam, 96, 54, what="massive 30k")
+    hit = op["id"] != ob.MISS
+    assert hit.sum() > 100 and np.all(op["id"][hit] < 10000)  # the first copy always wins the tie
+
+
+def test_trace_boxes_moving_and_lod(core, ob, rt):
+    """Boxes only (the reference's procedural scenes), last three moving (wgsl:442-461), LOD cull on (wgsl:147-155),
+    several times so the interpolated centres move."""
+    boxes = random_boxes(ob, 120, 3, extent=60.0, moving_last=3)
+    scene = setup_scene(core, ob, boxes, None)
+    for time in (0.0, 0.37, 2.9):
+        cam = rt.Camera((0, 20, 170), math.pi, -0.1).to_uniform(time, 108.0)
+        op, _, st = check_frame(core, ob, scene, cam, 192, 108, what=f"boxes t={time}")
+        assert st["primary_hits"] > 500 and st["box_tests"] > 0
+    far = rt.Camera((0, 20, 400), math.pi, -0.05).to_uniform(0.0, 108.0)  # beyond 200 units: everything culled
+    op, _, st = check_frame(core, ob, scene, far, 192, 108, what="boxes far")
+    assert st["primary_hits"] < 200
+
+
+def test_trace_mixed_scene(core, ob, rt):
+    boxes = random_boxes(ob, 60, 5, extent=45.0, moving_last=3)
+    tris = ob.generate_test_triangles(4000)
+    scene = setup_scene(core, ob, boxes, tris, cell_size=8.0)
+    cam = rt.Camera((10, 30, 140), math.pi, -0.2).to_uniform(1.1, 90.0)
+    op, _, st = check_frame(core, ob, scene, cam, 160, 90, what="mixed")
+    hit = op["id"][op["id"] != ob.MISS]
+    assert (hit < 60).sum() > 50 and (hit >= 60).sum() > 50
+
+
+@pytest.mark.parametrize("over", [dict(wgsl_compat=1), dict(lod_cull=0), dict(moving_box_count=0), dict(max_dda_steps=7),
+                                  dict(shadow_offset=0.05), dict(max_objects_per_cell=3)])
+def test_trace_parameter_variants(rt, ob, over):
+    core = rt.TraceCore(0, rt.default_params(**over))
+    boxes = random_boxes(ob, 40, 11, extent=45.0, moving_last=3)
+    tris = ob.generate_test_triangles(3000)
+    core.set_scene(boxes, tris)
+    core.build_grid(cell_size=8.0, max_per_cell=8192)
+    scene = ob.Scene(boxes, tris, cell_size=8.0)
+    cam = rt.Camera((10, 30, 140), math.pi, -0.2).to_uniform(0.6, 90.0)
+    check_frame(core, ob, scene, cam, 160, 90, what=str(over))
+    core.close()
+
+
+def test_stats_equal_oracle_counts(core, ob, rt, car_xyz9):
+    scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, 135.0)
+    core.set_collect_stats(True)
+    _, _, st = check_frame(core, ob, scene, cam, 240, 135, what="stats")
+    got = core.stats()
+    assert got == st, (got, st)
+    core.set_collect_stats(False)
+
+
+def test_debug_pixel(core, ob, rt, car_xyz9):
+    """raytracer_unified.wgsl:695-709 geometry fields."""
+    scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, 90.0)
+    for px, py in ((80, 45), (0, 0), (120, 60), (159, 89)):
+        got = core.debug_pixel(cam, 160, 90, px, py)
+        want = ob.debug_pixel(scene, ocam(ob, cam), 160, 90, px, py)
+        assert bytes(got) == bytes(want), (px, py)
+
+
+# ------------------------------------------------------------------------------ grids supplied by the caller
+
+def test_caller_supplied_grids(core, ob, rt):
+    """rt_set_grid_dense (the reference's FineCellData[] upload) and rt_set_grid_csr give the same picture."""
+    tris = ob.pyramid_triangles()
+    boxes = random_boxes(ob, 5, 9, extent=6.0)
+    grid = ob.Grid(boxes, tris, cell_size=4.0)
+    scene = ob.Scene(boxes, tris, grid=grid)
+    cam = rt.Camera.for_scene("pyramid").to_uniform(0.0, 48.0)
+    want, wshadow, _ = ob.trace_primary(scene, ocam(ob, cam), 80, 48)
+    core.set_scene(boxes, tris)
+    core.set_grid_dense(grid.meta, grid.dense)
+    p, s = core.trace_primary(cam, 80, 48)
+    assert_hits_equal(p, want, "dense grid")
+    assert_hits_equal(s, wshadow, "dense grid")
+    core.set_scene(boxes, tris)
+    with pytest.raises(rt.RtError):
+        core.trace_primary(cam, 80, 48)  # new scene, no grid yet
+    core.set_grid_csr(grid.meta, grid.cell_start, grid.indices)
+    p, s = core.trace_primary(cam, 80, 48)
+    assert_hits_equal(p, want, "csr grid")
+    tg = ob.Grid(None, tris, cell_size=4.0, mode=ob.GRID_TRIANGLES)
+    core.set_scene(None, tris)
+    core.set_grid_dense(tg.meta, tg.dense, tri_cells=True)
+    p, _ = core.trace_primary(cam, 80, 48)
+    want, _, _ = ob.trace_primary(ob.Scene(None, tris, grid=tg), ocam(ob, cam), 80, 48)
+    assert_hits_equal(p, want, "triangle-grid dense")
+
+
+def test_out_of_range_ids_are_skipped(core, ob, rt):
+    """A cell list naming a triangle past the array: skipped (raytracer_unified.wgsl:549)."""
+    tris = ob.pyramid_triangles()
+    grid = ob.Grid(None, tris)
+    idx = np.concatenate([grid.indices, [17, 6]]).astype(np.uint32)
+    cs = grid.cell_start.copy()
+    cs[-1] += 2
+    core.set_scene(None, tris)
+    core.set_grid_csr(grid.meta, cs, idx)
+    cam = rt.Camera.for_scene("pyramid").to_uniform(0.0, 36.0)
+    p, _ = core.trace_primary(cam, 64, 36)
+    want, _, _ = ob.trace_primary(ob.Scene(None, tris, grid=grid), ocam(ob, cam), 64, 36)
+    assert_hits_equal(p, want)
+
+
+# ------------------------------------------------------------------------------ ray lists
+
+def test_trace_rays_reference_generators(core, ob, golden):
+    """examples/massive_benchmark.rs:82-98: generate_test_rays against generate_test_triangles."""
+    tris = ob.generate_test_triangles(10000)
+    scene = setup_scene(core, ob, None, tris)
+    o, d = ob.generate_test_rays(1000)
+    got = core.trace_rays(o, d)
+    assert_hits_equal(got, golden["bench10k_rays1000_hits"], "golden ray list")
+    o, d = ob.generate_test_rays(50000)
+    want, _ = ob.trace_rays(scene, o, d)
+    assert_hits_equal(core.trace_rays(o, d), want, "50k rays closest")
+    want, _ = ob.trace_rays(scene, o, d, any_hit=True)
+    assert_hits_equal(core.trace_rays(o, d, any_hit=True), want, "50k rays any-hit")
+    assert (want["id"] != ob.MISS).sum() > 1000
+
+
+def test_trace_rays_degenerate_directions(core, ob, car_xyz9):
+    """Axis-aligned, signed-zero and tiny components; origins inside, outside and on the bounds."""
+    scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))
+    bmin, bmax = np.array(scene.grid.meta.bounds_min), np.array(scene.grid.meta.bounds_max)
+    o = [(0, 500, 0), (0, 100, 0), (0, 100, 0), (0, 100, 0), (-2000, 100, 0), (0, 100, 2000), tuple(bmax), tuple(bmin),
+         (0, 100, 0), (0, 100, 0), (5000, 5000, 5000), (0, 100, 0)]
+    d = [(0, -1, 0), (0, -1, -0.0), (-0.0, -1, 0), (1e-9, -1, -1e-9), (1, 0, 0), (0, 0, -1), (-0.57735026,) * 3,
+         (0.57735026,) * 3, (0, 1, 0), (1, 0, -0.0), (0.57735026,) * 3, (0, 0, 0)]
+    o, d = np.array(o, np.float32), np.array(d, np.float32)
+    for any_hit in (False, True):
+        want, _ = ob.trace_rays(scene, o, d, any_hit=any_hit)
+        assert_hits_equal(core.trace_rays(o, d, any_hit=any_hit), want, f"degenerate any={any_hit}")
+
+
+# ------------------------------------------------------------------------------ shards, device buffers, full size
+
+def test_shards_match_oracle_and_assemble(core, ob, rt, car_xyz9):
+    import torch
+    scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))
+    w, h, tw, th, n = 250, 141, 64, 64, 3
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+    full, full_s, _ = check_frame(core, ob, scene, cam, w, h, what="full")
+    per_rank = max(rt.shard_pixels(w, h, rt.RtShard(tw, th, r, n)) for r in range(n))
+    gathered = torch.full((n, per_rank, 2), -1, dtype=torch.int32, device="cuda")
+    gathered_s = torch.full((n, per_rank, 2), -1, dtype=torch.int32, device="cuda")
+    for r in range(n):
+        sh = rt.RtShard(tw, th, r, n)
+        check_frame(core, ob, scene, cam, w, h, shard=sh, what=f"shard {r}")
+        core.trace_primary(cam, w, h, shard=sh, out_primary=gathered[r], out_shadow=gathered_s[r])
+    image = torch.empty((h * w, 2), dtype=torch.int32, device="cuda")
+    core.assemble_tiles(gathered, w, h, tw, th, n, image)
+    core.sync()
+    assert_hits_equal(image.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), full, "assembled primary")
+    core.assemble_tiles(gathered_s, w, h, tw, th, n, image)
+    core.sync()
+    assert_hits_equal(image.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), full_s, "assembled shadow")
+
+
+def test_full_size_properties_1080p(core, ob, rt, car_xyz9):
+    """At BASELINE's frame size: repeatable, row bands == whole frame, counters consistent."""
+    import torch
+    core.set_scene(None, rt.triangles_from_xyz9(car_xyz9))
+    core.build_grid()
+    w, h = 1920, 1080
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+    a = torch.empty((w * h, 2), dtype=torch.int32, device="cuda")
+    b = torch.empty_like(a)
+    sa, sb = torch.empty_like(a), torch.empty_like(a)
+    core.trace_primary(cam, w, h, out_primary=a, out_shadow=sa)
+    core.trace_primary(cam, w, h, out_primary=b, out_shadow=sb)
+    core.sync()
+    assert torch.equal(a, b) and torch.equal(sa, sb)
+    bands = torch.empty_like(a)
+    for r in range(2):  # 8-row bands dealt to two "ranks", written straight to their place
+        sh = rt.RtShard(w, 8, r, 2)
+        n = rt.shard_pixels(w, h, sh)
+        tmp = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+        core.trace_primary(cam, w, h, shard=sh, shadow=False, out_primary=tmp)
+        core.sync()
+        rows = tmp.view(-1, 8, w, 2)
+        for j in range(rows.shape[0]):
+            y0 = (r + 2 * j) * 8
+            k = min(8, h - y0)
+            bands.view(h, w, 2)[y0:y0 + k] = rows[j, :k]
+    assert torch.equal(bands, a)
+    core.set_collect_stats(True)
+    p, s = core.trace_primary(cam, w, h)
+    st = core.stats()
+    core.set_collect_stats(False)
+    assert st["primary_hits"] == int((p["id"] != rt.RT_MISS).sum()) == st["shadow_rays"]
+    assert st["shadow_hits"] == int((s["id"] != rt.RT_MISS).sum())
+    assert st["rays"] == w * h + st["shadow_rays"]
+    assert np.array_equal(a.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), p)
+    hit = p["id"] != rt.RT_MISS
+    assert np.all(p["t"][hit] > 0) and np.all(p["id"][hit] < 3132) and np.all(s["id"][~hit] == rt.RT_MISS)
+
+
+def test_runs_on_torch_stream(core, ob, rt, car_xyz9):
+    import torch
+    scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, 90.0)
+    s = torch.cuda.Stream()
+    core.set_stream(s.cuda_stream)
+    out = torch.empty((160 * 90, 2), dtype=torch.int32, device="cuda")
+    with torch.cuda.stream(s):
+        core.trace_primary(cam, 160, 90, shadow=False, out_primary=out)
+    s.synchronize()
+    want, _, _ = ob.trace_primary(scene, ocam(ob, cam), 160, 90, shadow=False)
+    assert_hits_equal(out.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want)
+    core.set_stream(None)
+
+
+def test_errors_are_reported(core, rt, ob):
+    with pytest.raises(rt.RtError) as e:
+        core.trace_primary(rt.Camera.for_scene("gltf").to_uniform(), 8, 8)
+    assert e.value.code == -4 and "grid" in str(e.value)
+    core.set_scene(None, ob.pyramid_triangles())
+    meta = ob.Grid(None, ob.pyramid_triangles()).meta
+    with pytest.raises(rt.RtError):
+        core.set_grid_csr(meta, np.array([5, 3], np.uint32), np.zeros(5, np.uint32))  # decreasing offsets
+    with pytest.raises(rt.RtError):
+        core.update_vertices(np.zeros((7, 9), np.float32))  # more triangles than the scene has

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s at 1920x1080, primary + shadow rays, bundled static model.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one whole frame: W*H primary rays through the DDA grid plus one shadow ray per primary
+hit, all inside one kernel launch, with scene, grid and output buffers resident in HBM. At N > 1
+the SAME frame is cut into 64x64 tiles dealt round-robin to the ranks and gathered on rank 0
+(total work fixed: strong scaling). Prints one JSON line on rank 0.
+
+The frame's work (cells visited, candidates tested, rays) is counted by the kernel's own counters in an
+untimed launch. The CPU oracle is used for one thing only, outside the timed region: the `cpu_baseline`
+leg times the reference's CPU trace path (BVH build + both-children traversal, restated in oracle/) on
+the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WIDTH, HEIGHT = 1920, 1080
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+TILE = 64
+
+
+def algorithmic_bytes(stats):
+    """Per launch: 8 B per visited cell record, 4 B index + 36 B vertices per triangle candidate
+    (24 B per box candidate), 8 B hit record per ray."""
+    return 8 * stats["cells_visited"] + 40 * stats["tri_tests"] + 28 * stats["box_tests"] + 8 * stats["rays"]
+
+
+def cpu_baseline(xyz9, width, height):
+    """The reference's CPU trace path (binned-SAH BVH, recursive both-children traversal, Moller-Trumbore
+    leaves; examples/massive_benchmark.rs:62-98,226-270) on this frame's primary + shadow rays, all host
+    cores, rays chunked per thread. 2 warm-up + 5 timed passes as the example does, bounded to ~20 s."""
+    from oracle import binding as ob
+    cores = min(os.cpu_count() or 1, 16)
+    tris = ob.triangles_from_xyz9(xyz9)
+    scene = ob.Scene(None, tris)
+    cam = ob.camera_to_uniform((200, 200, 300), 3.35, -0.28, 0.0, float(height))
+    p, _, st, so, sd = ob.trace_primary(scene, cam, width, height, want_shadow_rays=True, n_threads=cores)
+    o, d = ob.primary_rays(cam, width, height)
+    hit = p["id"] != ob.MISS
+    ro, rd = np.concatenate([o, so[hit]]), np.concatenate([d, sd[hit]])
+    bvh = ob.Bvh(tris)
+    t0 = time.perf_counter()
+    bvh.trace(ro[::64], rd[::64], n_threads=cores)
+    probe = (time.perf_counter() - t0) * 64  # estimated seconds for one full pass
+    stride = max(1, int(np.ceil(probe * 7 / 20.0)))  # 7 passes within ~20 s
+    ro, rd = np.ascontiguousarray(ro[::stride]), np.ascontiguousarray(rd[::stride])
+    for _ in range(2):
+        bvh.trace(ro, rd, n_threads=cores)
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        bvh.trace(ro, rd, n_threads=cores)
+        times.append(time.perf_counter() - t0)
+    mean = float(np.mean(times))
+    # like-for-like: the oracle's own grid traversal, same rays, same cores
+    t0 = time.perf_counter()
+    ob.trace_rays(scene, ro, rd, n_threads=cores)
+    dda = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    r1, d1 = np.ascontiguousarray(ro[::8 * cores]), np.ascontiguousarray(rd[::8 * cores])  # spread over the frame
+    n1 = len(r1)
+    t0 = time.perf_counter()
+    bvh.trace(r1, d1, n_threads=1)
+    one = time.perf_counter() - t0
+    return {"value": len(ro) / mean / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"every {stride}th of the frame's {len(p) + int(hit.sum())} primary+shadow rays "
+                      f"({len(ro)} rays), BVH build + both-children traversal, mean of 5 passes",
+            "min_ms": min(times) * 1e3, "max_ms": max(times) * 1e3,
+            "single_thread_Mrays": n1 / one / 1e6, "grid_traversal_port_Mrays": len(ro) / dda / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    import ray_tracer_amd as rt
+    from ray_tracer_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    xyz9 = np.load(os.path.join(ROOT, "tests", "golden", "car_tris.npy"))
+    tris = rt.triangles_from_xyz9(xyz9) if rank == 0 else None
+    if world > 1:  # scene replicated by one RCCL broadcast, grid binned locally on every GPU
+        _, tris = sharding.broadcast_scene(np.zeros(0, rt.BOX_DTYPE) if rank == 0 else None, tris, dev)
+    core = rt.TraceCore(local_rank)
+    core.set_scene(None, tris)
+    meta, n_cells, n_refs = core.build_grid()
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(HEIGHT))
+
+    # the frame's work, counted by the kernel itself (untimed)
+    core.set_collect_stats(True)
+    core.trace_primary(cam, WIDTH, HEIGHT, shadow=True)
+    stats = core.stats()
+    core.set_collect_stats(False)
+    rays_per_frame = stats["rays"]
+
+    if world == 1:
+        prim = torch.empty((WIDTH * HEIGHT, 2), dtype=torch.int32, device=dev)
+        shad = torch.empty_like(prim)
+
+        def step():
+            core.trace_primary(cam, WIDTH, HEIGHT, shadow=True, out_primary=prim, out_shadow=shad)
+
+        def sync():
+            core.sync()
+    else:
+        sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True)
+
+        def step():
+            sh.trace(cam)
+
+        def sync():
+            sh.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    core.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    kernel_ms = core.timer_end() / args.steps  # HIP events on the launch stream
+    sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays_per_frame * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mrays/sec @1080p primary+shadow", "value": value, "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic camera path on the "
+            "reference's bundled static model (models/no_animation, 3132 triangles, flattened to a fixture)",
+            "config": {"workload": "configs[1]: static model, 1920x1080 primary rays through the DDA uniform grid "
+                                   "+ one shadow ray per primary hit, SCENE=gltf start camera",
+                       "width": WIDTH, "height": HEIGHT, "rays_per_frame": rays_per_frame,
+                       "primary_hits": stats["primary_hits"], "grid": list(meta.fine_dims), "cell_size": 16.0,
+                       "cells": n_cells, "cell_refs": n_refs,
+                       "parallelism": "single GPU" if world == 1 else f"{TILE}x{TILE} tiles round-robin over {world} GPUs, RCCL gather to rank 0"},
+        }
+        if world == 1:
+            abytes = algorithmic_bytes(stats)
+            achieved = abytes / (kernel_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("k_trace_primary_bytes_per_launch")
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "k_trace_primary<shadow>", "kernel_ms": kernel_ms,
+                               "algorithmic_bytes_per_launch": abytes, "cells_visited": stats["cells_visited"],
+                               "tri_tests": stats["tri_tests"]}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(xyz9, WIDTH, HEIGHT)
+        print(json.dumps(out), flush=True)
+    core.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -177,10 +177,11 @@ int rt_trace_rays(rt_ctx* ctx, const CameraUniform* camera, const float* origins
 
 /* Reassembles a frame from shard outputs: gathered holds, rank after rank, each rank's
  * packed output of rt_trace_primary with shard {tile_w,tile_h,first=rank,stride=n_ranks};
- * every rank's block is padded to ceil(n_tiles/n_ranks) tiles. image: width*height
- * row-major. Both device pointers. No reference counterpart (single GPU there). */
+ * rank r's block starts at record r*rank_stride (rank_stride = 0 means blocks are packed
+ * back to back, each padded to ceil(n_tiles/n_ranks) tiles). image: width*height row-major.
+ * Both device pointers. No reference counterpart (single GPU there). */
 int rt_assemble_tiles(rt_ctx* ctx, const rt_hit* gathered, uint32_t width, uint32_t height,
-                      uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, rt_hit* image);
+                      uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, rt_hit* image);
 
 /* Fills *info for one pixel the way the shader's debug pixel does
  * (raytracer_unified.wgsl:695-709), geometry fields only (hit_color is zero). */

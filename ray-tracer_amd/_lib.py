@@ -94,7 +94,7 @@ PROTOTYPES = {
     "rt_update_vertices": (_I, [_VP, _VP, _U32, _U32]),
     "rt_trace_primary": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), _VP, _VP]),
     "rt_trace_rays": (_I, [_VP, C.POINTER(CameraUniform), _VP, _VP, _U32, _VP, _I]),
-    "rt_assemble_tiles": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _VP]),
+    "rt_assemble_tiles": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
     "rt_debug_pixel": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, _U32, _U32, C.POINTER(RayDebugInfo)]),
     "rt_get_stats": (_I, [_VP, C.POINTER(RtStats)]),
     "rt_set_collect_stats": (_I, [_VP, _I]),

@@ -653,14 +653,16 @@ extern "C" int rt_trace_rays(rt_ctx* c, const CameraUniform* cam, const float* o
 }
 
 extern "C" int rt_assemble_tiles(rt_ctx* c, const rt_hit* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
-                                 uint32_t tile_h, uint32_t n_ranks, rt_hit* image) {
+                                 uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, rt_hit* image) {
     if (int r = use(c)) return r;
     if (!gathered || !image || !width || !height || !tile_w || !tile_h || !n_ranks)
         return fail(c, RT_ERR_INVALID, "rt_assemble_tiles: NULL or zero argument");
     if (!is_device_ptr(gathered) || !is_device_ptr(image))
         return fail(c, RT_ERR_INVALID, "rt_assemble_tiles: both buffers must be device memory");
     const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
-    const size_t per_rank = (size_t)((tiles_x * tiles_y + n_ranks - 1) / n_ranks) * tile_w * tile_h;
+    const size_t min_stride = (size_t)((tiles_x * tiles_y + n_ranks - 1) / n_ranks) * tile_w * tile_h;
+    const size_t per_rank = rank_stride ? rank_stride : min_stride;
+    if (per_rank < min_stride) return fail(c, RT_ERR_INVALID, "rt_assemble_tiles: rank_stride smaller than one rank's block");
     hipLaunchKernelGGL(k_assemble, dim3((width + 255) / 256, height), dim3(256), 0, c->stream,
                        reinterpret_cast<const uint2*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks,
                        per_rank, reinterpret_cast<uint2*>(image));

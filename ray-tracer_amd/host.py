@@ -225,8 +225,9 @@ class TraceCore:
                                        _ptr(out), int(any_hit)))
         return out
 
-    def assemble_tiles(self, gathered, width, height, tile_w, tile_h, n_ranks, image):
-        self._ck(self._L.rt_assemble_tiles(self._h, _ptr(gathered), width, height, tile_w, tile_h, n_ranks, _ptr(image)))
+    def assemble_tiles(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride=0):
+        self._ck(self._L.rt_assemble_tiles(self._h, _ptr(gathered), width, height, tile_w, tile_h, n_ranks, rank_stride,
+                                           _ptr(image)))
 
     def debug_pixel(self, cam, width, height, px, py):
         info = RayDebugInfo()

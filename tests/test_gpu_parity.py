@@ -409,7 +409,7 @@ def test_shards_match_oracle_and_assemble(core, ob, rt, car_xyz9):
         check_frame(core, ob, scene, cam, w, h, shard=sh, what=f"shard {r}")
         core.trace_primary(cam, w, h, shard=sh, out_primary=gathered[r], out_shadow=gathered_s[r])
     image = torch.empty((h * w, 2), dtype=torch.int32, device="cuda")
-    core.assemble_tiles(gathered, w, h, tw, th, n, image)
+    core.assemble_tiles(gathered, w, h, tw, th, n, image, rank_stride=per_rank)
     core.sync()
     assert_hits_equal(image.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), full, "assembled primary")
     core.assemble_tiles(gathered_s, w, h, tw, th, n, image)

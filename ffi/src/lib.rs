@@ -1,0 +1,77 @@
+//! `extern "C"` declarations of include/rt_mi355.h plus a small safe wrapper.
+//! The renderer's own `#[repr(C)]` Pod structs (src/types.rs, src/grid.rs) are passed as raw bytes;
+//! nothing is re-declared here except the handful of structs the ABI adds.
+use std::ffi::{c_char, c_int, c_void, CStr};
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, bytemuck::Pod, bytemuck::Zeroable)]
+pub struct RtHit { pub id: u32, pub t: f32 }
+pub const RT_MISS: u32 = 0xFFFF_FFFF;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct RtParams {
+    pub finest_cell_size: f32, pub max_objects_per_cell: u32, pub max_dda_steps: u32, pub wgsl_compat: u32,
+    pub lod_cull: u32, pub moving_box_count: u32, pub fov: f32, pub light_direction: [f32; 3],
+    pub shadow_offset: f32, pub collect_stats: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct RtShard { pub tile_w: u32, pub tile_h: u32, pub first: u32, pub stride: u32 }
+
+#[repr(C)]
+pub struct RtCtx { _private: [u8; 0] }
+
+extern "C" {
+    pub fn rt_default_params(p: *mut RtParams);
+    pub fn rt_create(out: *mut *mut RtCtx, device_id: c_int, params: *const RtParams) -> c_int;
+    pub fn rt_destroy(ctx: *mut RtCtx);
+    pub fn rt_last_error(ctx: *const RtCtx) -> *const c_char;
+    pub fn rt_create_error() -> *const c_char;
+    pub fn rt_sync(ctx: *mut RtCtx) -> c_int;
+    pub fn rt_set_scene(ctx: *mut RtCtx, boxes: *const c_void, nb: u32, tris: *const c_void, nt: u32) -> c_int;
+    pub fn rt_set_grid_dense(ctx: *mut RtCtx, meta: *const c_void, fine_cells: *const c_void, n_cells: usize) -> c_int;
+    pub fn rt_set_grid_csr(ctx: *mut RtCtx, meta: *const c_void, cell_start: *const u32, indices: *const u32) -> c_int;
+    pub fn rt_build_grid(ctx: *mut RtCtx, cell_size: f32, max_per_cell: u32, mode: c_int) -> c_int;
+    pub fn rt_update_vertices(ctx: *mut RtCtx, xyz9: *const f32, first: u32, count: u32) -> c_int;
+    pub fn rt_trace_primary(ctx: *mut RtCtx, camera: *const c_void, width: u32, height: u32, shard: *const RtShard,
+                            out_primary: *mut RtHit, out_shadow: *mut RtHit) -> c_int;
+    pub fn rt_trace_rays(ctx: *mut RtCtx, camera: *const c_void, origins: *const f32, dirs: *const f32, n: u32,
+                         out: *mut RtHit, any_hit: c_int) -> c_int;
+}
+
+/// Owns one context. `Send` but not `Sync`: the C side is not re-entrant (one in-order stream).
+pub struct TraceCore { ctx: *mut RtCtx }
+unsafe impl Send for TraceCore {}
+
+impl TraceCore {
+    pub fn new(device_id: i32) -> Result<Self, String> {
+        let mut ctx = std::ptr::null_mut();
+        let rc = unsafe { rt_create(&mut ctx, device_id, std::ptr::null()) };
+        if rc != 0 { return Err(unsafe { CStr::from_ptr(rt_create_error()) }.to_string_lossy().into_owned()); }
+        Ok(Self { ctx })
+    }
+    fn check(&self, rc: c_int) -> Result<(), String> {
+        if rc == 0 { Ok(()) } else { Err(unsafe { CStr::from_ptr(rt_last_error(self.ctx)) }.to_string_lossy().into_owned()) }
+    }
+    /// `boxes` / `triangles`: `bytemuck::cast_slice(&Vec<BoxData>)` / `(&Vec<TriangleData>)`.
+    pub fn set_scene(&mut self, boxes: &[u8], triangles: &[u8]) -> Result<(), String> {
+        assert!(boxes.len() % 96 == 0 && triangles.len() % 80 == 0);
+        self.check(unsafe { rt_set_scene(self.ctx, boxes.as_ptr().cast(), (boxes.len() / 96) as u32,
+                                         triangles.as_ptr().cast(), (triangles.len() / 80) as u32) })
+    }
+    /// On-GPU replacement of `HierarchicalGrid::build` (mode 0) / `TriangleGrid::build` (mode 1).
+    pub fn build_grid(&mut self) -> Result<(), String> { self.check(unsafe { rt_build_grid(self.ctx, 0.0, 0, 0) }) }
+    /// `camera`: `bytemuck::bytes_of(&CameraUniform)`. Returns (primary, shadow) hit records, row-major.
+    pub fn trace_primary(&self, camera: &[u8], width: u32, height: u32) -> Result<(Vec<RtHit>, Vec<RtHit>), String> {
+        assert_eq!(camera.len(), 80);
+        let n = (width * height) as usize;
+        let (mut p, mut s) = (vec![RtHit::default(); n], vec![RtHit::default(); n]);
+        self.check(unsafe { rt_trace_primary(self.ctx, camera.as_ptr().cast(), width, height, std::ptr::null(),
+                                             p.as_mut_ptr(), s.as_mut_ptr()) })?;
+        Ok((p, s))
+    }
+}
+
+impl Drop for TraceCore { fn drop(&mut self) { unsafe { rt_destroy(self.ctx) } } }

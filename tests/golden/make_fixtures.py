@@ -8,8 +8,8 @@ Run in the build container (needs /root/reference for the two bundled models):
    triangles, float32 (n, 9) = v0,v1,v2. This restates what the reference's loader does
    with positions (src/loaders/gltf_triangles.rs:179-283): walk the scene's node tree,
    global = parent * local (column-major 4x4), transform_point3 every POSITION, then emit
-   one triangle per index triple. All nodes of both models carry `matrix` (or nothing),
-   never TRS. Arithmetic is float32 in glam's scalar order; glam's SIMD Mat4 on the
+   one triangle per index triple. Every node above a mesh carries `matrix` (or nothing); only
+   skeleton joints use TRS. Arithmetic is float32 in glam's scalar order; glam's SIMD Mat4 on the
    author's machine may round the last bit differently, so these vertices are INPUT data
    for both the oracle and the GPU path, not a pinned output of the reference.
    Models: "Old Rusty Car" by Renafox (CC-BY-NC-4.0), "phoenix bird" by NORBERTO-3D

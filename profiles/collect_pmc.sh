@@ -1,0 +1,21 @@
+#!/bin/bash
+# Hardware-counter passes for the headline workload, one rocprofv3 run per pass (counters are never
+# combined with tracing). Run on the GPU box from the repository root:
+#   bash profiles/collect_pmc.sh <tag>
+# Results: gpurun_out/pmc_<tag>/<pass>/..._counter_collection.csv ; summarise with profiles/summarize_pmc.py
+set -u
+TAG=${1:-run}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+pass() {
+  name=$1; shift
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/$name.log" 2>&1
+  echo "pass $name rc=$?"
+}
+pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY || exit 1
+pass sq2 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_INST_CYCLES_VMEM_RD || exit 1
+pass tcc_rd FETCH_SIZE TCC_HIT_sum GRBM_GUI_ACTIVE || exit 1
+pass tcc_wr WRITE_SIZE TCC_MISS_sum TCC_REQ_sum || exit 1
+pass tcp TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum TA_BUSY_avr || exit 1

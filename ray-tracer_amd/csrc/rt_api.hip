@@ -560,8 +560,8 @@ extern "C" int rt_trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t wi
     const ShardMap m = make_shard(width, height, shard);
     const size_t n_out = (size_t)m.n_local * m.tile_w * m.tile_h;
     if (n_out == 0) return RT_OK;
-    const uint64_t waves = (uint64_t)m.n_local * m.sub_x * m.sub_y;
-    if (waves > 0x3FFFFFFFull) return fail(c, RT_ERR_LIMIT, "rt_trace_primary: frame too large");
+    const uint64_t blocks = (uint64_t)m.n_local * ((m.sub_x + 1) / 2) * ((m.sub_y + 1) / 2);  // 16x16 pixels each
+    if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "rt_trace_primary: frame too large");
 
     const bool host_p = !is_device_ptr(out_primary);
     const bool host_s = out_shadow && !is_device_ptr(out_shadow);
@@ -582,7 +582,7 @@ extern "C" int rt_trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t wi
 
     const DevScene s = make_scene(c);
     const DevFrame f = make_frame(c, cam, width, height);
-    const dim3 grid((uint32_t)((waves + 3) / 4));
+    const dim3 grid((uint32_t)blocks);
     const bool wgsl = c->params.wgsl_compat != 0;
     if (out_shadow) {
         if (wgsl)

@@ -228,24 +228,21 @@ __device__ inline void flush_stats(unsigned long long* stats, unsigned long long
     }
 }
 
-// Blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of logical blocks
-// so neighbouring image regions - which walk the same grid cells - meet in one L2.
-__device__ inline uint32_t xcd_remap(uint32_t b, uint32_t nblocks) {
-    const uint32_t q = nblocks / 8, r = nblocks % 8, xcd = b % 8;
-    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + b / 8;
-}
-
-// One lane per pixel, one wave per 8x8 pixel block, four waves per workgroup.
+// One lane per pixel, one wave per 8x8 pixel block, four waves (a 16x16 pixel block) per workgroup.
+// Workgroups are dealt to the XCDs round-robin in launch order, so neighbouring 16x16 blocks run on
+// different XCDs at the same time: cheap (sky) and expensive (dense geometry) image regions are spread
+// evenly over the chip. (Giving each XCD one contiguous band of the image instead left most XCDs idle
+// behind the one that owned the geometry: 30 % average occupancy on the headline frame.)
 template <bool WGSL, bool SHADOW, bool STATS>
 __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
                                                        uint2* __restrict__ out_s, unsigned long long* stats) {
-    const uint32_t block = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t wave = block * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint32_t sub_per_tile = m.sub_x * m.sub_y;
-    if (wave >= m.n_local * sub_per_tile) return;
-    const uint32_t lt = wave / sub_per_tile, sub = wave % sub_per_tile;
-    const uint32_t lx = (sub % m.sub_x) * 8 + (lane & 7), ly = (sub / m.sub_x) * 8 + (lane >> 3);
+    const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
+    const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;  // 16x16 blocks per tile
+    const uint32_t blk_per_tile = blk_x * blk_y;
+    const uint32_t lt = blockIdx.x / blk_per_tile, blk = blockIdx.x % blk_per_tile;
+    if (lt >= m.n_local) return;
+    const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
+    const uint32_t lx = sub_x * 8 + (lane & 7), ly = sub_y * 8 + (lane >> 3);
     const uint32_t tile = m.first + lt * m.stride;
     const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
     const bool in_tile = lx < m.tile_w && ly < m.tile_h;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_mi355.so")
+LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "librt_mi355.so")  # override: development builds only
 
 f32 = np.float32
 u32 = np.uint32

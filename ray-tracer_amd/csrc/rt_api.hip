@@ -5,6 +5,12 @@
 #include <vector>
 
 #include "rt_internal.hpp"
+#ifdef RT_EXPERIMENTS
+#include <cstdlib>
+#include <type_traits>
+
+#include "rt_trace_variants.hpp"
+#endif
 
 using namespace rt;
 
@@ -222,14 +228,29 @@ int fetch_stats(rt_ctx* c) {
     return RT_OK;
 }
 
+// Kernel variants: WGSL (constant set), SHADOW / ANY, BOXES (scene has boxes). The counting build is the
+// general one (with the box path).
 template <bool WGSL, bool SHADOW>
 void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* op,
                     uint2* os) {
     unsigned long long* st = c->stats.as<unsigned long long>();
+#ifdef RT_EXPERIMENTS
+    if (const char* v = getenv("RT_VARIANT")) {
+        if (!WGSL && SHADOW && !stats && s.nb == 0) {
+            switch (atoi(v)) {
+#define RT_VAR(N) case N: hipLaunchKernelGGL((k_trace_primary_var<N>), grid, dim3(256), 0, c->stream, s, f, m, op, os); return;
+                RT_VARIANT_LIST
+#undef RT_VAR
+            }
+        }
+    }
+#endif
     if (stats)
-        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+    else if (s.nb != 0)
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
     else
-        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
 }
 
 template <bool WGSL, bool ANY>
@@ -237,9 +258,11 @@ void launch_rays(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const floa
                  uint2* out) {
     unsigned long long* st = c->stats.as<unsigned long long>();
     if (stats)
-        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+    else if (s.nb != 0)
+        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
     else
-        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, false>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
 }
 
 // Stage a host array on the device (or pass a device pointer through).

@@ -81,21 +81,26 @@ __host__ __device__ inline float slab(V3 o, V3 inv, V3 bmin, V3 bmax) {
 // reference: src/core/triangle_intersection.rs:31-82 (WGSL = false: eps 1e-6, reject t < eps)
 // and raytracer_unified.wgsl:238-277 (WGSL = true: eps 1e-5, accept t > eps).
 // Returns t, or -1 when the triangle is rejected.
+// The reference rejects step by step (determinant, u, v, t). Every value here is produced by the same
+// operations in the same order, so accepted hits carry identical bits; only the control flow is flatter:
+// the reciprocal is taken before the determinant test (its value is unused when that test fails) and there
+// is one branch, after the u range test, which most candidates fail.
 template <bool WGSL>
 __host__ __device__ inline float moller_trumbore(V3 o, V3 d, V3 v0, V3 e1, V3 e2) {
     const float eps = WGSL ? 0.00001f : 1e-6f;
-    V3 h = cross(d, e2);
-    float a = dot(e1, h);
-    if (fabsf(a) < eps) return -1.0f;
-    float f = 1.0f / a;
-    V3 s = o - v0;
-    float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return -1.0f;
-    V3 q = cross(s, e1);
-    float v = f * dot(d, q);
-    if (v < 0.0f || u + v > 1.0f) return -1.0f;
-    float t = f * dot(e2, q);
-    if (WGSL ? !(t > eps) : (t < eps)) return -1.0f;
+    const V3 h = cross(d, e2);
+    const float a = dot(e1, h);
+    const float f = 1.0f / a;
+    const V3 s = o - v0;
+    const float u = f * dot(s, h);
+    float t = -1.0f;
+    if (!(fabsf(a) < eps) && !(u < 0.0f || u > 1.0f)) {
+        const V3 q = cross(s, e1);
+        const float v = f * dot(d, q);
+        const float tt = f * dot(e2, q);
+        const bool t_ok = WGSL ? (tt > eps) : !(tt < eps);
+        if (!(v < 0.0f || u + v > 1.0f) && t_ok) t = tt;
+    }
     return t;
 }
 

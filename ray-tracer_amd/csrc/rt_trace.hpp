@@ -56,31 +56,40 @@ struct HitRec {
     uint32_t ref;  // index of the winning reference record (triangles) - used to rebuild the normal
 };
 
-// One ray through the grid. ANY: stop at the first accepted intersection.
-// Returns true on a hit. Mirrors raytracer_unified.wgsl:430-588 statement by statement.
-template <bool WGSL, bool ANY, bool STATS>
+// One ray through the grid; mirrors raytracer_unified.wgsl:430-588.
+//
+// What limits this loop on gfx950 is instruction issue (vector AND scalar: every divergent `if` costs
+// exec-mask bookkeeping on the scalar unit), not memory: the scene is cache resident and eight waves per SIMD
+// hide the load latency. So the loop is written to be short:
+//   - the DDA step is branch-free (three selects instead of an if / else-if / else ladder),
+//   - the flattened cell index is kept incrementally (wrapping u32, equal to x + y*gx + z*gx*gy mod 2^32),
+//   - coordinates are compared as unsigned, so stepping to -1 is "outside" by the same test as stepping to g,
+//   - "have a hit" is best_id != MISS, not a separate flag,
+//   - a candidate's three 16-byte loads are issued together.
+// ANY: stop at the first accepted intersection. BOXES: scene has boxes (pre-pass + box candidates).
+// Returns true on a hit.
+template <bool WGSL, bool ANY, bool STATS, bool BOXES>
 __device__ inline bool trace_ray(const DevScene& s, V3 o, V3 d, HitRec& out, Counters& ctr) {
-    bool hit = false;
     float closest = 1e10f;
     uint32_t best_id = MISS, best_ref = MISS;
     const V3 inv = v3(safe_inv<WGSL>(d.x), safe_inv<WGSL>(d.y), safe_inv<WGSL>(d.z));
-    ctr.steps = 0;
+    if (STATS) ctr.steps = 0;
 
     // moving boxes are tested directly, before the grid (:442-461)
-    for (uint32_t i = s.moving_start; i < s.nb; ++i) {
-        ctr.steps++;
-        const float4 b0 = s.box_frame[4 * i], b1 = s.box_frame[4 * i + 1];
-        if (!(__float_as_uint(b0.w) & BOX_CULLED_PREPASS)) {
-            if (STATS) ctr.box++;
-            float t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
-            if (t >= 0.0f && t < closest) {
-                closest = t;
-                best_id = i;
-                best_ref = MISS;
-                hit = true;
-                if (ANY) {
-                    out = HitRec{closest, best_id, best_ref};
-                    return true;
+    if (BOXES) {
+        for (uint32_t i = s.moving_start; i < s.nb; ++i) {
+            if (STATS) ctr.steps++;
+            const float4 b0 = s.box_frame[4 * i], b1 = s.box_frame[4 * i + 1];
+            if (!(__float_as_uint(b0.w) & BOX_CULLED_PREPASS)) {
+                if (STATS) ctr.box++;
+                const float t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
+                if (t >= 0.0f && t < closest) {
+                    closest = t;
+                    best_id = i;
+                    if (ANY) {
+                        out = HitRec{closest, best_id, MISS};
+                        return true;
+                    }
                 }
             }
         }
@@ -93,7 +102,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, V3 d, HitRec& out, Cou
     V3 pos = o;
     float t_off = 0.0f;
     if (pos.x < bmin.x || pos.x > bmax.x || pos.y < bmin.y || pos.y > bmax.y || pos.z < bmin.z || pos.z > bmax.z) {
-        float t_entry = slab(o, inv, bmin, bmax);
+        const float t_entry = slab(o, inv, bmin, bmax);
         if (t_entry < 0.0f) return false;
         t_off = t_entry + 0.001f;
         pos = o + d * t_off;
@@ -104,38 +113,42 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, V3 d, HitRec& out, Cou
     // DDA set-up (:492-517)
     uint32_t cx, cy, cz;
     {
-        V3 rel = pos - bmin;
-        float ics = 1.0f / fmaxf(cs, 1e-8f);
+        const V3 rel = pos - bmin;
+        const float ics = 1.0f / fmaxf(cs, 1e-8f);
         cx = f2u_sat(fmaxf(0.0f, floorf(rel.x * ics)));
         cy = f2u_sat(fmaxf(0.0f, floorf(rel.y * ics)));
         cz = f2u_sat(fmaxf(0.0f, floorf(rel.z * ics)));
     }
-    const int sx = d.x >= 0.0f ? 1 : -1, sy = d.y >= 0.0f ? 1 : -1, sz = d.z >= 0.0f ? 1 : -1;
-    V3 cell_world = bmin + v3((float)cx, (float)cy, (float)cz) * cs;
-    V3 next_b = cell_world + v3(sx > 0 ? cs : 0.0f, sy > 0 ? cs : 0.0f, sz > 0 ? cs : 0.0f);
+    const bool px = d.x >= 0.0f, py = d.y >= 0.0f, pz = d.z >= 0.0f;
+    const V3 cell_world = bmin + v3((float)cx, (float)cy, (float)cz) * cs;
+    const V3 next_b = cell_world + v3(px ? cs : 0.0f, py ? cs : 0.0f, pz ? cs : 0.0f);
     const V3 t_delta = vabs(inv * cs);
     V3 t_max = v3(t_off, t_off, t_off) + (next_b - pos) * inv;
     {
-        float fl = t_off + 0.00001f;
+        const float fl = t_off + 0.00001f;
         t_max = vmax(t_max, v3(fl, fl, fl));
     }
+    // per-ray step constants: +-1 per axis and the matching change of the flattened index
+    const uint32_t sx = px ? 1u : 0xFFFFFFFFu, sy = py ? 1u : 0xFFFFFFFFu, sz = pz ? 1u : 0xFFFFFFFFu;
+    const uint32_t dix = sx, diy = sy * s.gx, diz = sz * (s.gx * s.gy);
+    uint32_t idx = cx + cy * s.gx + cz * s.gx * s.gy;  // get_fine_index (:406-409), wrapping
 
     // traversal (:520-588)
     for (uint32_t i = 0; i < s.max_steps; ++i) {
-        ctr.steps++;
-        if (STATS) ctr.cells++;
-        // flattened index in wrapping u32 arithmetic; past the array = empty cell
-        uint32_t idx = cx + cy * s.gx + cz * s.gx * s.gy;
+        if (STATS) {
+            ctr.steps++;
+            ctr.cells++;
+        }
         uint2 cell = make_uint2(0u, 0u);
-        if (idx < s.n_cells) cell = s.cells[idx];
-        uint32_t n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
+        if (idx < s.n_cells) cell = s.cells[idx];  // past the array = empty cell
+        const uint32_t n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
         for (uint32_t j = 0; j < n; ++j) {
             const uint32_t r = cell.x + j;
-            const float4 q0 = s.refs[3 * r];
+            const float4 q0 = s.refs[3 * r], q1 = s.refs[3 * r + 1], q2 = s.refs[3 * r + 2];
             const uint32_t id = __float_as_uint(q0.w);
-            float t = -1.0f;
-            if (id < s.nb) {
+            if (BOXES && id < s.nb) {
                 const float4 b0 = s.box_frame[4 * id], b1 = s.box_frame[4 * id + 1];
+                float t = -1.0f;
                 if (!(__float_as_uint(b0.w) & BOX_CULLED_GRID)) {
                     if (STATS) ctr.box++;
                     t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
@@ -144,49 +157,41 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, V3 d, HitRec& out, Cou
                     closest = t;
                     best_id = id;
                     best_ref = MISS;
-                    hit = true;
-                    if (ANY) {
-                        out = HitRec{closest, best_id, best_ref};
-                        return true;
-                    }
+                    if (ANY) break;
                 }
-            } else if (id != REF_INVALID) {
-                if (STATS) ctr.tri++;
-                const float4 q1 = s.refs[3 * r + 1], q2 = s.refs[3 * r + 2];
-                t = moller_trumbore<WGSL>(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z));
-                if (t > 0.0f && t < closest) {
+            } else {
+                if (STATS && id != REF_INVALID) ctr.tri++;
+                const float t = moller_trumbore<WGSL>(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z),
+                                                      v3(q2.x, q2.y, q2.z));
+                if (t > 0.0f && t < closest && id != REF_INVALID) {
                     closest = t;
                     best_id = id;
                     best_ref = r;
-                    hit = true;
-                    if (ANY) {
-                        out = HitRec{closest, best_id, best_ref};
-                        return true;
-                    }
+                    if (ANY) break;
                 }
             }
         }
-        if (hit && closest < fminf(fminf(t_max.x, t_max.y), t_max.z)) break;
-
-        if (t_max.x < t_max.y && t_max.x < t_max.z) {
-            int nx = (int)cx + sx;
-            if (nx < 0 || nx >= (int)s.gx) break;
-            cx = (uint32_t)nx;
-            t_max.x += t_delta.x;
-        } else if (t_max.y < t_max.z) {
-            int ny = (int)cy + sy;
-            if (ny < 0 || ny >= (int)s.gy) break;
-            cy = (uint32_t)ny;
-            t_max.y += t_delta.y;
-        } else {
-            int nz = (int)cz + sz;
-            if (nz < 0 || nz >= (int)s.gz) break;
-            cz = (uint32_t)nz;
-            t_max.z += t_delta.z;
-        }
+        if (ANY && best_id != MISS) break;
+        // early-out (:561)
+        if (best_id != MISS && closest < fminf(fminf(t_max.x, t_max.y), t_max.z)) break;
+        // step one axis (:566-587): x if tx < ty and tx < tz, else y if ty < tz, else z
+        const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
+        const bool ay = !ax && t_max.y < t_max.z;
+        const uint32_t c = ax ? cx : (ay ? cy : cz);
+        const uint32_t st = ax ? sx : (ay ? sy : sz);
+        const uint32_t g = ax ? s.gx : (ay ? s.gy : s.gz);
+        const uint32_t nc = c + st;
+        if (nc >= g) break;  // left the grid (either side)
+        cx = ax ? nc : cx;
+        cy = ay ? nc : cy;
+        cz = (ax || ay) ? cz : nc;
+        idx += ax ? dix : (ay ? diy : diz);
+        t_max.x = ax ? t_max.x + t_delta.x : t_max.x;
+        t_max.y = ay ? t_max.y + t_delta.y : t_max.y;
+        t_max.z = (ax || ay) ? t_max.z : t_max.z + t_delta.z;
     }
     out = HitRec{closest, best_id, best_ref};
-    return hit;
+    return best_id != MISS;
 }
 
 // Geometric normal of a hit (triangle: normalize(e1 x e2), :277; box: axis of largest |p|-half, :218-227).
@@ -233,14 +238,14 @@ __device__ inline void flush_stats(unsigned long long* stats, unsigned long long
 // different XCDs at the same time: cheap (sky) and expensive (dense geometry) image regions are spread
 // evenly over the chip. (Giving each XCD one contiguous band of the image instead left most XCDs idle
 // behind the one that owned the geometry: 30 % average occupancy on the headline frame.)
-template <bool WGSL, bool SHADOW, bool STATS>
+template <bool WGSL, bool SHADOW, bool STATS, bool BOXES>
 __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
                                                        uint2* __restrict__ out_s, unsigned long long* stats) {
     const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
     const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;  // 16x16 blocks per tile
     const uint32_t blk_per_tile = blk_x * blk_y;
     const uint32_t lt = blockIdx.x / blk_per_tile, blk = blockIdx.x % blk_per_tile;
-    if (lt >= m.n_local) return;
+    if (lt >= m.n_local) return;  // whole workgroup
     const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
     const uint32_t lx = sub_x * 8 + (lane & 7), ly = sub_y * 8 + (lane >> 3);
     const uint32_t tile = m.first + lt * m.stride;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
         const V3 d = primary_dir(f, px, py);
         HitRec h;
         n_rays++;
-        if (trace_ray<WGSL, false, STATS>(s, o, d, h, ctr)) {
+        if (trace_ray<WGSL, false, STATS, BOXES>(s, o, d, h, ctr)) {
             n_ph++;
             ph = make_uint2(h.id, __float_as_uint(h.t));
             if (SHADOW) {
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
                 HitRec oh;
                 n_rays++;
                 n_sr++;
-                if (trace_ray<WGSL, true, STATS>(s, so, sd, oh, ctr)) {
+                if (trace_ray<WGSL, true, STATS, BOXES>(s, so, sd, oh, ctr)) {
                     n_sh++;
                     sh = make_uint2(oh.id, __float_as_uint(oh.t));
                 }
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
 }
 
 // Explicit ray list: one lane per ray.
-template <bool WGSL, bool ANY, bool STATS>
+template <bool WGSL, bool ANY, bool STATS, bool BOXES>
 __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __restrict__ origins,
                                                     const float* __restrict__ dirs, uint32_t n,
                                                     uint2* __restrict__ out, unsigned long long* stats) {
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __r
     if (i < n) {
         HitRec h;
         n_rays = 1;
-        bool hit = trace_ray<WGSL, ANY, STATS>(s, ld3(origins + 3 * (size_t)i), ld3(dirs + 3 * (size_t)i), h, ctr);
+        bool hit = trace_ray<WGSL, ANY, STATS, BOXES>(s, ld3(origins + 3 * (size_t)i), ld3(dirs + 3 * (size_t)i), h, ctr);
         n_hit = hit ? 1 : 0;
         out[i] = hit ? make_uint2(h.id, __float_as_uint(h.t)) : make_uint2(MISS, 0u);
     }
@@ -309,7 +314,7 @@ __global__ void k_debug_pixel(DevScene s, DevFrame f, uint32_t px, uint32_t py, 
     const V3 d = primary_dir(f, px, py);
     HitRec h;
     Counters ctr{0, 0, 0, 0};
-    const bool hit = trace_ray<WGSL, false, false>(s, o, d, h, ctr);
+    const bool hit = trace_ray<WGSL, false, true, true>(s, o, d, h, ctr);
     for (int k = 0; k < 20; ++k) info20[k] = 0.0f;
     info20[0] = o.x, info20[1] = o.y, info20[2] = o.z;
     info20[3] = hit ? 1.0f : 0.0f;

@@ -1,0 +1,51 @@
+// DEVELOPMENT ONLY (built with -DRT_EXPERIMENTS into librt_mi355_exp.so, never shipped):
+// alternative shapes of the traversal loop, timed against each other in one process by tools/variants_bench.py.
+#pragma once
+#include "rt_trace.hpp"
+
+namespace rt {
+
+// VARIANT 0: the shipped trace_ray
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_trace_primary_var(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
+                                                           uint2* __restrict__ out_s) {
+    const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
+    const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;
+    const uint32_t blk_per_tile = blk_x * blk_y;
+    const uint32_t lt = blockIdx.x / blk_per_tile, blk = blockIdx.x % blk_per_tile;
+    if (lt >= m.n_local) return;
+    const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
+    const uint32_t lx = sub_x * 8 + (lane & 7), ly = sub_y * 8 + (lane >> 3);
+    const uint32_t tile = m.first + lt * m.stride;
+    const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
+    const bool in_tile = lx < m.tile_w && ly < m.tile_h;
+    const bool live = in_tile && px < f.width && py < f.height;
+    uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
+    Counters ctr{0, 0, 0, 0};
+    auto trace = [&](V3 o, V3 d, HitRec& h, auto any) -> bool {
+        constexpr bool ANY = decltype(any)::value;
+        return trace_ray<false, ANY, false, false>(s, o, d, h, ctr);
+    };
+    if (live) {
+        const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+        const V3 d = primary_dir(f, px, py);
+        HitRec h;
+        if (trace(o, d, h, std::false_type{})) {
+            ph = make_uint2(h.id, __float_as_uint(h.t));
+            const V3 pos = o + d * h.t;
+            V3 n = hit_normal(s, h, pos);
+            if (dot(n, d) > 0.0f) n = neg(n);
+            const V3 so = pos + n * f.shadow_offset;
+            const V3 sd = v3(f.shadow_dir[0], f.shadow_dir[1], f.shadow_dir[2]);
+            HitRec oh;
+            if (trace(so, sd, oh, std::true_type{})) sh = make_uint2(oh.id, __float_as_uint(oh.t));
+        }
+    }
+    if (in_tile) {
+        const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
+        out_p[oi] = ph;
+        out_s[oi] = sh;
+    }
+}
+
+}  // namespace rt

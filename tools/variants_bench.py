@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Development tool: times kernel-shape variants of the primary+shadow trace against each other in ONE process,
+interleaved rounds, on the headline frame. Needs `make -C ray-tracer_amd/csrc exp` and
+RT_LIB_PATH=ray-tracer_amd/librt_mi355_exp.so. Every variant is checked against variant-less output first."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RT_LIB_PATH", os.path.join(ROOT, "ray-tracer_amd", "librt_mi355_exp.so"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import ray_tracer_amd as rt  # noqa: E402
+
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2]
+rounds, steps = 7, 50
+W, H = 1920, 1080
+core = rt.TraceCore(0)
+core.set_scene(None, rt.triangles_from_xyz9(np.load(os.path.join(ROOT, "tests/golden/car_tris.npy"))))
+core.build_grid()
+cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
+p = torch.empty((W * H, 2), dtype=torch.int32, device="cuda")
+s = torch.empty_like(p)
+os.environ.pop("RT_VARIANT", None)
+core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
+core.sync()
+ref_p, ref_s = p.clone(), s.clone()
+times = {v: [] for v in variants}
+for v in variants:
+    os.environ["RT_VARIANT"] = str(v)
+    p.zero_(); s.zero_()
+    core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
+    core.sync()
+    ok = torch.equal(p, ref_p) and torch.equal(s, ref_s)
+    print(f"variant {v}: {'bit-identical' if ok else 'MISMATCH'}", flush=True)
+for r in range(rounds):
+    for v in variants:
+        os.environ["RT_VARIANT"] = str(v)
+        for _ in range(5):
+            core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
+        core.timer_begin()
+        for _ in range(steps):
+            core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
+        times[v].append(core.timer_end() / steps * 1e3)
+for v in variants:
+    t = np.array(times[v])
+    print(f"variant {v}: median {np.median(t):7.1f} us  min {t.min():7.1f} us")

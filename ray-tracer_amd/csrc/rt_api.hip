@@ -83,6 +83,15 @@ __global__ void k_box_frame(const BoxData* __restrict__ boxes, uint32_t nb, floa
     out[4 * (size_t)i + 3] = make_float4(half.x, half.y, half.z, 0.f);
 }
 
+// Geometric normal per triangle: normalize(cross(v1 - v0, v2 - v0)) (src/core/triangle_intersection.rs:79).
+__global__ void k_tri_normals(const float* __restrict__ tri_v, uint32_t first, uint32_t count, float4* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float* v = tri_v + 9 * (size_t)(first + i);
+    const V3 v0 = ld3(v), n = normalize(cross(ld3(v + 3) - v0, ld3(v + 6) - v0));
+    out[first + i] = make_float4(n.x, n.y, n.z, 0.f);
+}
+
 __global__ void k_tri_unpack(const TriangleData* __restrict__ tris, uint32_t nt, float* __restrict__ tri_v) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nt) return;
@@ -141,6 +150,7 @@ DevScene make_scene(const rt_ctx* c) {
     memset(&s, 0, sizeof(s));
     s.refs = c->refs.as<float4>();
     s.cells = c->cells.as<uint2>();
+    s.tri_normal = c->tri_n.as<float4>();
     s.box_frame = c->box_frame.as<float4>();
     s.nb = c->grid_nb;
     s.nt = c->nt;
@@ -157,11 +167,13 @@ DevScene make_scene(const rt_ctx* c) {
         s.bmax[k] = c->meta.bounds_max[k];
     }
     s.cell_size = c->meta.finest_cell_size;
+    s.inv_cell_size = 1.0f / fmaxf(s.cell_size, 1e-8f);  // raytracer_unified.wgsl:384
     return s;
 }
 
 // Per-frame constants the shader evaluates per pixel; evaluated once here with the host libm.
 DevFrame make_frame(const rt_ctx* c, const CameraUniform* cam, uint32_t w, uint32_t h) {
+    const uint32_t gx = c->meta.grid_sizes[RT_GRID_LEVELS - 1][0], gy = c->meta.grid_sizes[RT_GRID_LEVELS - 1][1];
     DevFrame f;
     memset(&f, 0, sizeof(f));
     if (cam) {
@@ -173,8 +185,9 @@ DevFrame make_frame(const rt_ctx* c, const CameraUniform* cam, uint32_t w, uint3
         }
     }
     f.fov_scale = tanf(c->params.fov);                       // raytracer_unified.wgsl:643
-    V3 sd = neg(normalize(ld3(c->params.light_direction)));  // raytracer_unified.wgsl:599-600
-    f.shadow_dir[0] = sd.x, f.shadow_dir[1] = sd.y, f.shadow_dir[2] = sd.z;
+    const V3 sd = neg(normalize(ld3(c->params.light_direction)));  // raytracer_unified.wgsl:599-600
+    f.shadow = c->params.wgsl_compat ? make_ray_dir<true>(sd, c->meta.finest_cell_size, gx, gy)
+                                     : make_ray_dir<false>(sd, c->meta.finest_cell_size, gx, gy);
     f.shadow_offset = c->params.shadow_offset;
     f.width = w;
     f.height = h;
@@ -372,7 +385,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
+    DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->tri_n,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
                       &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->out_p,     &c->out_s,
                       &c->in_o,      &c->in_d,      &c->stats,      &c->misc};
@@ -446,6 +459,10 @@ extern "C" int rt_set_scene(rt_ctx* c, const BoxData* boxes, uint32_t nb, const 
         RT_HIP(c, hipMemcpyAsync(c->misc.p, tris, (size_t)nt * sizeof(TriangleData), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_tri_unpack, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->misc.as<TriangleData>(), nt,
                            c->tri_v.as<float>());
+        RT_HIP(c, hipGetLastError());
+        RT_HIP(c, c->tri_n.reserve((size_t)nt * sizeof(float4)));
+        hipLaunchKernelGGL(k_tri_normals, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->tri_v.as<float>(), 0u, nt,
+                           c->tri_n.as<float4>());
         RT_HIP(c, hipGetLastError());
     }
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -565,6 +582,9 @@ extern "C" int rt_update_vertices(rt_ctx* c, const float* xyz9, uint32_t first, 
     const bool dev = is_device_ptr(xyz9);
     RT_HIP(c, hipMemcpyAsync(c->tri_v.as<float>() + 9 * (size_t)first, xyz9, (size_t)count * 9 * sizeof(float),
                              dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_tri_normals, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->tri_v.as<float>(), first,
+                       count, c->tri_n.as<float4>());
+    RT_HIP(c, hipGetLastError());
     if (!dev) RT_HIP(c, hipStreamSynchronize(c->stream));
     c->has_grid = false;  // cell lists and reference records are stale now
     return RT_OK;

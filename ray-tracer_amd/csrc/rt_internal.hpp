@@ -59,6 +59,7 @@ struct rt_ctx {
     uint32_t grid_nb = 0;  // boxes numbered ahead of the triangles in the current grid's ids (0 for a triangle-only grid)
     rt::DevBuf boxes;  // BoxData[nb]
     rt::DevBuf tri_v;  // float[nt*9]: v0,v1,v2
+    rt::DevBuf tri_n;  // float4[nt]: geometric normal
 
     // grid
     bool has_grid = false;

@@ -39,9 +39,17 @@ __host__ __device__ inline V3 mix(V3 a, V3 b, float t) { return a * (1.0f - t) +
 
 // float -> u32, saturating, NaN -> 0 (Rust `as u32`, WGSL u32())
 __host__ __device__ inline uint32_t f2u_sat(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cvt_u32_f32 has exactly these semantics (NaN and negatives -> 0, too large -> 0xFFFFFFFF); a plain cast
+    // is undefined for out-of-range input, so the instruction is named explicitly
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
     if (!(x > 0.0f)) return 0u;
     if (x >= 4294967296.0f) return 0xFFFFFFFFu;
     return (uint32_t)x;
+#endif
 }
 // float -> i32, saturating, NaN -> 0 (Rust `as i32`)
 __host__ __device__ inline int32_t f2i_sat(float x) {

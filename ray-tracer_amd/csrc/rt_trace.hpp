@@ -9,6 +9,7 @@
 //   refs[3*r..]   one 48-byte record per (cell, object) reference, stored in cell order so a
 //                 cell's candidates are contiguous:  (v0.xyz, id bits) (e1.xyz, 0) (e2.xyz, 0)
 //                 for a triangle, (0,0,0, id bits) for a box (box data is per frame, below)
+//   tri_normal[k] per triangle k: (normalize(e1 x e2), 0) - read once per primary hit to place the shadow ray
 //   box_frame[4*b..] per box, recomputed each frame: (lo.xyz, flag bits) (hi.xyz, 0)
 //                 (centre.xyz, 0) (half.xyz, 0) with lo/hi = interpolated centre -/+ half
 #pragma once
@@ -25,18 +26,44 @@ constexpr uint32_t BOX_CULLED_PREPASS = 2u;    // LOD cull outcome in the moving
 struct DevScene {
     const float4* refs;
     const uint2* cells;
+    const float4* tri_normal;  // per triangle: normalize(e1 x e2), evaluated once when the scene is uploaded
     const float4* box_frame;
     uint32_t nb, nt, n_cells, n_refs;
     uint32_t gx, gy, gz;
     uint32_t max_per_cell, max_steps, moving_start;
     float bmin[3], bmax[3];
     float cell_size;
+    float inv_cell_size;  // 1 / max(cell_size, 1e-8), evaluated once on the host
 };
+
+// Direction-dependent constants of a ray (raytracer_unified.wgsl:494-515). Per lane for primary rays; for shadow
+// rays the direction is the same for the whole frame, so the host evaluates them once and they live in scalar
+// registers.
+struct RayDir {
+    V3 d, inv, t_delta;     // direction, safe inverse, |cell_size * inv|
+    uint32_t sx, sy, sz;    // +1 / -1 (as 0xFFFFFFFF) per axis
+    uint32_t dix, diy, diz; // change of the flattened cell index for a step along each axis
+};
+
+template <bool WGSL>
+__host__ __device__ inline RayDir make_ray_dir(V3 d, float cell_size, uint32_t gx, uint32_t gy) {
+    RayDir r;
+    r.d = d;
+    r.inv = v3(safe_inv<WGSL>(d.x), safe_inv<WGSL>(d.y), safe_inv<WGSL>(d.z));
+    r.t_delta = vabs(r.inv * cell_size);
+    r.sx = d.x >= 0.0f ? 1u : 0xFFFFFFFFu;
+    r.sy = d.y >= 0.0f ? 1u : 0xFFFFFFFFu;
+    r.sz = d.z >= 0.0f ? 1u : 0xFFFFFFFFu;
+    r.dix = r.sx;
+    r.diy = r.sy * gx;
+    r.diz = r.sz * (gx * gy);
+    return r;
+}
 
 struct DevFrame {
     float cam_pos[3], fwd[3], right[3], up[3];
     float fov_scale;      // tan(fov), evaluated once on the host
-    float shadow_dir[3];  // -normalize(light_direction), evaluated once on the host
+    RayDir shadow;        // towards the light: -normalize(light_direction); evaluated once on the host
     float shadow_offset;
     uint32_t width, height;
 };
@@ -69,10 +96,10 @@ struct HitRec {
 // ANY: stop at the first accepted intersection. BOXES: scene has boxes (pre-pass + box candidates).
 // Returns true on a hit.
 template <bool WGSL, bool ANY, bool STATS, bool BOXES>
-__device__ inline bool trace_ray(const DevScene& s, V3 o, V3 d, HitRec& out, Counters& ctr) {
+__device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitRec& out, Counters& ctr) {
     float closest = 1e10f;
     uint32_t best_id = MISS, best_ref = MISS;
-    const V3 inv = v3(safe_inv<WGSL>(d.x), safe_inv<WGSL>(d.y), safe_inv<WGSL>(d.z));
+    const V3 d = rd.d, inv = rd.inv;
     if (STATS) ctr.steps = 0;
 
     // moving boxes are tested directly, before the grid (:442-461)
@@ -114,23 +141,20 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, V3 d, HitRec& out, Cou
     uint32_t cx, cy, cz;
     {
         const V3 rel = pos - bmin;
-        const float ics = 1.0f / fmaxf(cs, 1e-8f);
+        const float ics = s.inv_cell_size;
         cx = f2u_sat(fmaxf(0.0f, floorf(rel.x * ics)));
         cy = f2u_sat(fmaxf(0.0f, floorf(rel.y * ics)));
         cz = f2u_sat(fmaxf(0.0f, floorf(rel.z * ics)));
     }
-    const bool px = d.x >= 0.0f, py = d.y >= 0.0f, pz = d.z >= 0.0f;
+    const uint32_t sx = rd.sx, sy = rd.sy, sz = rd.sz, dix = rd.dix, diy = rd.diy, diz = rd.diz;
     const V3 cell_world = bmin + v3((float)cx, (float)cy, (float)cz) * cs;
-    const V3 next_b = cell_world + v3(px ? cs : 0.0f, py ? cs : 0.0f, pz ? cs : 0.0f);
-    const V3 t_delta = vabs(inv * cs);
+    const V3 next_b = cell_world + v3(sx == 1u ? cs : 0.0f, sy == 1u ? cs : 0.0f, sz == 1u ? cs : 0.0f);
+    const V3 t_delta = rd.t_delta;
     V3 t_max = v3(t_off, t_off, t_off) + (next_b - pos) * inv;
     {
         const float fl = t_off + 0.00001f;
         t_max = vmax(t_max, v3(fl, fl, fl));
     }
-    // per-ray step constants: +-1 per axis and the matching change of the flattened index
-    const uint32_t sx = px ? 1u : 0xFFFFFFFFu, sy = py ? 1u : 0xFFFFFFFFu, sz = pz ? 1u : 0xFFFFFFFFu;
-    const uint32_t dix = sx, diy = sy * s.gx, diz = sz * (s.gx * s.gy);
     uint32_t idx = cx + cy * s.gx + cz * s.gx * s.gy;  // get_fine_index (:406-409), wrapping
 
     // traversal (:520-588)
@@ -197,8 +221,8 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, V3 d, HitRec& out, Cou
 // Geometric normal of a hit (triangle: normalize(e1 x e2), :277; box: axis of largest |p|-half, :218-227).
 __device__ inline V3 hit_normal(const DevScene& s, const HitRec& h, V3 pos) {
     if (h.ref != MISS) {
-        const float4 q1 = s.refs[3 * h.ref + 1], q2 = s.refs[3 * h.ref + 2];
-        return normalize(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));
+        const float4 n = s.tri_normal[h.id - s.nb];
+        return v3(n.x, n.y, n.z);
     }
     const float4 c = s.box_frame[4 * h.id + 2], hf = s.box_frame[4 * h.id + 3];
     V3 p = pos - v3(c.x, c.y, c.z);
@@ -259,9 +283,10 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
     if (live) {
         const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         const V3 d = primary_dir(f, px, py);
+        const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.gx, s.gy);
         HitRec h;
         n_rays++;
-        if (trace_ray<WGSL, false, STATS, BOXES>(s, o, d, h, ctr)) {
+        if (trace_ray<WGSL, false, STATS, BOXES>(s, o, rd, h, ctr)) {
             n_ph++;
             ph = make_uint2(h.id, __float_as_uint(h.t));
             if (SHADOW) {
@@ -269,11 +294,10 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
                 V3 n = hit_normal(s, h, pos);
                 if (dot(n, d) > 0.0f) n = neg(n);
                 const V3 so = pos + n * f.shadow_offset;
-                const V3 sd = v3(f.shadow_dir[0], f.shadow_dir[1], f.shadow_dir[2]);
                 HitRec oh;
                 n_rays++;
                 n_sr++;
-                if (trace_ray<WGSL, true, STATS, BOXES>(s, so, sd, oh, ctr)) {
+                if (trace_ray<WGSL, true, STATS, BOXES>(s, so, f.shadow, oh, ctr)) {
                     n_sh++;
                     sh = make_uint2(oh.id, __float_as_uint(oh.t));
                 }
@@ -299,7 +323,8 @@ __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __r
     if (i < n) {
         HitRec h;
         n_rays = 1;
-        bool hit = trace_ray<WGSL, ANY, STATS, BOXES>(s, ld3(origins + 3 * (size_t)i), ld3(dirs + 3 * (size_t)i), h, ctr);
+        const RayDir rd = make_ray_dir<WGSL>(ld3(dirs + 3 * (size_t)i), s.cell_size, s.gx, s.gy);
+        bool hit = trace_ray<WGSL, ANY, STATS, BOXES>(s, ld3(origins + 3 * (size_t)i), rd, h, ctr);
         n_hit = hit ? 1 : 0;
         out[i] = hit ? make_uint2(h.id, __float_as_uint(h.t)) : make_uint2(MISS, 0u);
     }
@@ -314,7 +339,8 @@ __global__ void k_debug_pixel(DevScene s, DevFrame f, uint32_t px, uint32_t py, 
     const V3 d = primary_dir(f, px, py);
     HitRec h;
     Counters ctr{0, 0, 0, 0};
-    const bool hit = trace_ray<WGSL, false, true, true>(s, o, d, h, ctr);
+    const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.gx, s.gy);
+    const bool hit = trace_ray<WGSL, false, true, true>(s, o, rd, h, ctr);
     for (int k = 0; k < 20; ++k) info20[k] = 0.0f;
     info20[0] = o.x, info20[1] = o.y, info20[2] = o.z;
     info20[3] = hit ? 1.0f : 0.0f;

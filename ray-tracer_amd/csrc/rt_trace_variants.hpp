@@ -22,23 +22,23 @@ __global__ __launch_bounds__(256) void k_trace_primary_var(DevScene s, DevFrame 
     const bool live = in_tile && px < f.width && py < f.height;
     uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
     Counters ctr{0, 0, 0, 0};
-    auto trace = [&](V3 o, V3 d, HitRec& h, auto any) -> bool {
+    auto trace = [&](V3 o, const RayDir& rd, HitRec& h, auto any) -> bool {
         constexpr bool ANY = decltype(any)::value;
-        return trace_ray<false, ANY, false, false>(s, o, d, h, ctr);
+        return trace_ray<false, ANY, false, false>(s, o, rd, h, ctr);
     };
     if (live) {
         const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         const V3 d = primary_dir(f, px, py);
         HitRec h;
-        if (trace(o, d, h, std::false_type{})) {
+        const RayDir rd = make_ray_dir<false>(d, s.cell_size, s.gx, s.gy);
+        if (trace(o, rd, h, std::false_type{})) {
             ph = make_uint2(h.id, __float_as_uint(h.t));
             const V3 pos = o + d * h.t;
             V3 n = hit_normal(s, h, pos);
             if (dot(n, d) > 0.0f) n = neg(n);
             const V3 so = pos + n * f.shadow_offset;
-            const V3 sd = v3(f.shadow_dir[0], f.shadow_dir[1], f.shadow_dir[2]);
             HitRec oh;
-            if (trace(so, sd, oh, std::true_type{})) sh = make_uint2(oh.id, __float_as_uint(oh.t));
+            if (trace(so, f.shadow, oh, std::true_type{})) sh = make_uint2(oh.id, __float_as_uint(oh.t));
         }
     }
     if (in_tile) {

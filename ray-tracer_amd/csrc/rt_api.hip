@@ -251,7 +251,7 @@ void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const D
     if (const char* v = getenv("RT_VARIANT")) {
         if (!WGSL && SHADOW && !stats && s.nb == 0) {
             switch (atoi(v)) {
-#define RT_VAR(N) case N: hipLaunchKernelGGL((k_trace_primary_var<N>), grid, dim3(256), 0, c->stream, s, f, m, op, os); return;
+#define RT_VAR(N) case N: hipLaunchKernelGGL((k_trace_primary_var<N>), dim3(grid.x * (256 / VarCfg<N>::threads)), dim3(VarCfg<N>::threads), 0, c->stream, s, f, m, op, os); return;
                 RT_VARIANT_LIST
 #undef RT_VAR
             }
@@ -786,6 +786,32 @@ extern "C" int rt_intersect_tri_pairs(rt_ctx* c, const float* origins, const flo
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
+
+#ifdef RT_EXPERIMENTS
+// development only: read and clear the per-wave trip counters of the instrumented variant
+extern "C" int rt_dbg_trips(rt_ctx* c, unsigned long long* out8) {
+    if (int r = use(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(rt::g_trip), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {0};
+    RT_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(rt::g_trip), z, sizeof(z)));
+    return RT_OK;
+}
+extern "C" int rt_dbg_wave_trips(rt_ctx* c, unsigned int* out, size_t n) {
+    if (int r = use(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_wave_trips), n * sizeof(unsigned int)));
+    std::vector<unsigned int> z(n, 0u);
+    RT_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(rt::g_wave_trips), z.data(), n * sizeof(unsigned int)));
+    return RT_OK;
+}
+extern "C" int rt_dbg_wave_times(rt_ctx* c, unsigned long long* out, size_t n) {
+    if (int r = use(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_wave_t), n * sizeof(unsigned long long)));
+    return RT_OK;
+}
+#endif
 
 // ================================================================== timing
 

@@ -130,6 +130,44 @@ __global__ __launch_bounds__(256) void k_bin(BinGrid g, const BoxData* __restric
             }
 }
 
+// Re-test masks. A reference (cell C, object T) gets bit 2a (2a+1) set when the cell one step back along axis a
+// in the - (+) direction also lists T and lists it within the part of its list that is traversed. A ray that
+// ENTERS C through that face has therefore just tested T against the same ray: testing it again would give the
+// same t, which can neither beat the current closest hit (strict <) nor turn a rejection into a hit, so the
+// trace kernel skips it. T's cells form a box and a line crosses a box in one run of face-adjacent cells, so
+// "listed one step back" is the same as "already tested". Cells whose lists may have been cut by the per-cell
+// cap never vouch for their neighbours (their bits stay 0), which keeps the skip exact.
+__global__ void k_ref_masks(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                            const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ indices,
+                            uint32_t n_refs, uint32_t n_cells, uint32_t cap, float4* __restrict__ refs) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_refs) return;
+    // cell of this reference: last c with cell_start[c] <= r
+    uint32_t lo = 0, hi = n_cells;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (cell_start[mid] <= r) lo = mid; else hi = mid;
+    }
+    const uint32_t c = lo;
+    const uint32_t cc[3] = {c % g.gx, (c / g.gx) % g.gy, c / (g.gx * g.gy)};
+    const uint32_t stride[3] = {1u, g.gx, g.gx * g.gy};
+    V3 mn, mx;
+    object_bounds(boxes, tri_v, g.nb, indices[r], mn, mx);
+    const Range3 rg = cell_range(g, mn, mx);
+    uint32_t mask = 0;
+    for (int a = 0; a < 3; ++a) {
+        if ((int)cc[a] > rg.lo[a]) {  // arrived by a + step: previous cell is c - stride
+            const uint32_t p = c - stride[a];
+            if (cell_start[p + 1] - cell_start[p] < cap) mask |= 1u << (2 * a);
+        }
+        if ((int)cc[a] < rg.hi[a]) {  // arrived by a - step: previous cell is c + stride
+            const uint32_t p = c + stride[a];
+            if (cell_start[p + 1] - cell_start[p] < cap) mask |= 2u << (2 * a);
+        }
+    }
+    refs[3 * (size_t)r + 1].w = __uint_as_float(mask);
+}
+
 __global__ void k_clamp_counts(const uint32_t* __restrict__ counts, uint32_t n_cells, uint32_t cap,
                                uint32_t* __restrict__ clamped) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,6 +346,13 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
     // a triangle-only grid numbers its triangles from 0 and knows no boxes (src/grid_triangles.rs:92-99)
     c->grid_nb = nb;
     if (int r = emit_refs_from_csr(c)) return r;
+    if (n_refs) {
+        const uint32_t cap = std::min(max_per_cell, c->params.max_objects_per_cell);
+        hipLaunchKernelGGL(k_ref_masks, dim3((n_refs + 255) / 256), dim3(256), 0, st, g, c->boxes.as<BoxData>(),
+                           c->tri_v.as<float>(), (const uint32_t*)final_start, (const uint32_t*)c->indices.as<uint32_t>(),
+                           n_refs, n_cells, cap, c->refs.as<float4>());
+        RT_HIP(c, hipGetLastError());
+    }
     RT_HIP(c, hipStreamSynchronize(st));
     return RT_OK;
 }

@@ -8,7 +8,8 @@
 //   cells[c]      uint2 (first ref, ref count) per fine grid cell, c = x + y*gx + z*gx*gy
 //   refs[3*r..]   one 48-byte record per (cell, object) reference, stored in cell order so a
 //                 cell's candidates are contiguous:  (v0.xyz, id bits) (e1.xyz, 0) (e2.xyz, 0)
-//                 for a triangle, (0,0,0, id bits) for a box (box data is per frame, below)
+//                 for a triangle, (0,0,0, id bits) for a box (box data is per frame, below); the spare word of
+//                 the second quad holds the re-test mask (6 bits, see trace_ray)
 //   tri_normal[k] per triangle k: (normalize(e1 x e2), 0) - read once per primary hit to place the shadow ray
 //   box_frame[4*b..] per box, recomputed each frame: (lo.xyz, flag bits) (hi.xyz, 0)
 //                 (centre.xyz, 0) (half.xyz, 0) with lo/hi = interpolated centre -/+ half
@@ -85,18 +86,25 @@ struct HitRec {
 
 // One ray through the grid; mirrors raytracer_unified.wgsl:430-588.
 //
-// What limits this loop on gfx950 is instruction issue (vector AND scalar: every divergent `if` costs
-// exec-mask bookkeeping on the scalar unit), not memory: the scene is cache resident and eight waves per SIMD
-// hide the load latency. So the loop is written to be short:
-//   - the DDA step is branch-free (three selects instead of an if / else-if / else ladder),
+// Per-wave cost on gfx950 is set by instruction issue and by the length of the dependent chain of the
+// heaviest wave (a few 8x8 pixel blocks over the model's densest cells run 10-30x the average number of
+// candidate tests and finish last), not by memory bandwidth: the scene is cache resident. So:
+//   - the DDA step is branch-free (selects instead of an if / else-if / else ladder) and leaving the grid is
+//     detected with per-axis counters of the steps that remain, not by rebuilding cell coordinates,
 //   - the flattened cell index is kept incrementally (wrapping u32, equal to x + y*gx + z*gx*gy mod 2^32),
-//   - coordinates are compared as unsigned, so stepping to -1 is "outside" by the same test as stepping to g,
 //   - "have a hit" is best_id != MISS, not a separate flag,
-//   - a candidate's three 16-byte loads are issued together.
+//   - a candidate's 48-byte record is loaded while the previous candidate is tested,
+//   - SKIP: a candidate that the ray already tested in the cell it just left is not tested again. The shader
+//     re-tests it, gets the same t, and that t can neither beat the closest hit under its strict '<' nor turn
+//     a rejection into a hit, so skipping changes nothing. The per-reference mask in q1.w says through which
+//     faces of this cell a ray can arrive having already met the object (see k_ref_masks in rt_build.hip);
+//     it is 0 (never skip) for grids supplied by the caller.
 // ANY: stop at the first accepted intersection. BOXES: scene has boxes (pre-pass + box candidates).
-// Returns true on a hit.
+// STATS: count what the REFERENCE algorithm does (no skipping), for parity of the counters and for the
+// algorithmic byte count. Returns true on a hit.
 template <bool WGSL, bool ANY, bool STATS, bool BOXES>
 __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitRec& out, Counters& ctr) {
+    constexpr bool SKIP = !STATS;
     float closest = 1e10f;
     uint32_t best_id = MISS, best_ref = MISS;
     const V3 d = rd.d, inv = rd.inv;
@@ -156,63 +164,81 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         t_max = vmax(t_max, v3(fl, fl, fl));
     }
     uint32_t idx = cx + cy * s.gx + cz * s.gx * s.gy;  // get_fine_index (:406-409), wrapping
+    // Steps that can still be taken along each axis before the shader's test (next < 0 || next >= g, :568-583)
+    // ends the traversal. A start cell outside the grid (only possible for an origin on the far bounds) can take
+    // none in the + direction; in the - direction it can step only if that lands inside (c - 1 < g).
+    uint32_t rx = sx == 1u ? (cx < s.gx ? s.gx - 1u - cx : 0u) : (cx > s.gx ? 0u : cx);
+    uint32_t ry = sy == 1u ? (cy < s.gy ? s.gy - 1u - cy : 0u) : (cy > s.gy ? 0u : cy);
+    uint32_t rz = sz == 1u ? (cz < s.gz ? s.gz - 1u - cz : 0u) : (cz > s.gz ? 0u : cz);
+    // face through which the current cell was entered, as a bit of the re-test mask (0 = start cell)
+    const uint32_t mx = sx == 1u ? 1u : 2u, my = sy == 1u ? 4u : 8u, mz = sz == 1u ? 16u : 32u;
+    uint32_t arrival = 0;
 
     // traversal (:520-588)
+    uint2 cell = make_uint2(0u, 0u);
+    if (idx < s.n_cells) cell = s.cells[idx];  // past the array = empty cell
     for (uint32_t i = 0; i < s.max_steps; ++i) {
         if (STATS) {
             ctr.steps++;
             ctr.cells++;
         }
-        uint2 cell = make_uint2(0u, 0u);
-        if (idx < s.n_cells) cell = s.cells[idx];  // past the array = empty cell
+        // The step this iteration ends with (:566-587: x if tx < ty and tx < tz, else y if ty < tz, else z)
+        // depends on t_max only; deciding it before the candidate loop keeps it off the loop's exit path.
+        const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
+        const bool ay = !ax && t_max.y < t_max.z;
+        const bool az = !ax && !ay;
+        const uint32_t rem = ax ? rx : (ay ? ry : rz);
+        const uint32_t idx_next = idx + (ax ? dix : (ay ? diy : diz));
         const uint32_t n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t r = cell.x + j;
-            const float4 q0 = s.refs[3 * r], q1 = s.refs[3 * r + 1], q2 = s.refs[3 * r + 2];
-            const uint32_t id = __float_as_uint(q0.w);
-            if (BOXES && id < s.nb) {
-                const float4 b0 = s.box_frame[4 * id], b1 = s.box_frame[4 * id + 1];
-                float t = -1.0f;
-                if (!(__float_as_uint(b0.w) & BOX_CULLED_GRID)) {
-                    if (STATS) ctr.box++;
-                    t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
-                }
-                if (t >= 0.0f && t < closest) {
-                    closest = t;
-                    best_id = id;
-                    best_ref = MISS;
-                    if (ANY) break;
-                }
-            } else {
-                if (STATS && id != REF_INVALID) ctr.tri++;
-                const float t = moller_trumbore<WGSL>(o, d, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z),
-                                                      v3(q2.x, q2.y, q2.z));
-                if (t > 0.0f && t < closest && id != REF_INVALID) {
-                    closest = t;
-                    best_id = id;
-                    best_ref = r;
-                    if (ANY) break;
+        if (n) {
+            uint32_t r = cell.x;
+            float4 q0 = s.refs[3 * r], q1 = s.refs[3 * r + 1], q2 = s.refs[3 * r + 2];
+            for (uint32_t j = 0; j < n; ++j, ++r) {
+                const float4 c0 = q0, c1 = q1, c2 = q2;
+                // next record; one past the cell's list is still inside the array (padded by one record)
+                q0 = s.refs[3 * r + 3], q1 = s.refs[3 * r + 4], q2 = s.refs[3 * r + 5];
+                const uint32_t id = __float_as_uint(c0.w);
+                if (SKIP && (__float_as_uint(c1.w) & arrival)) continue;
+                if (BOXES && id < s.nb) {
+                    const float4 b0 = s.box_frame[4 * id], b1 = s.box_frame[4 * id + 1];
+                    float t = -1.0f;
+                    if (!(__float_as_uint(b0.w) & BOX_CULLED_GRID)) {
+                        if (STATS) ctr.box++;
+                        t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
+                    }
+                    if (t >= 0.0f && t < closest) {
+                        closest = t;
+                        best_id = id;
+                        best_ref = MISS;
+                        if (ANY) break;
+                    }
+                } else {
+                    if (STATS && id != REF_INVALID) ctr.tri++;
+                    const float t = moller_trumbore<WGSL>(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z),
+                                                          v3(c2.x, c2.y, c2.z));
+                    if (t > 0.0f && t < closest && id != REF_INVALID) {
+                        closest = t;
+                        best_id = id;
+                        best_ref = r;
+                        if (ANY) break;
+                    }
                 }
             }
         }
         if (ANY && best_id != MISS) break;
         // early-out (:561)
         if (best_id != MISS && closest < fminf(fminf(t_max.x, t_max.y), t_max.z)) break;
-        // step one axis (:566-587): x if tx < ty and tx < tz, else y if ty < tz, else z
-        const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
-        const bool ay = !ax && t_max.y < t_max.z;
-        const uint32_t c = ax ? cx : (ay ? cy : cz);
-        const uint32_t st = ax ? sx : (ay ? sy : sz);
-        const uint32_t g = ax ? s.gx : (ay ? s.gy : s.gz);
-        const uint32_t nc = c + st;
-        if (nc >= g) break;  // left the grid (either side)
-        cx = ax ? nc : cx;
-        cy = ay ? nc : cy;
-        cz = (ax || ay) ? cz : nc;
-        idx += ax ? dix : (ay ? diy : diz);
-        t_max.x = ax ? t_max.x + t_delta.x : t_max.x;
-        t_max.y = ay ? t_max.y + t_delta.y : t_max.y;
-        t_max.z = (ax || ay) ? t_max.z : t_max.z + t_delta.z;
+        if (rem == 0u) break;  // the step would leave the grid
+        rx -= ax ? 1u : 0u;
+        ry -= ay ? 1u : 0u;
+        rz -= az ? 1u : 0u;
+        idx = idx_next;
+        arrival = ax ? mx : (ay ? my : mz);
+        t_max.x += ax ? t_delta.x : 0.0f;
+        t_max.y += ay ? t_delta.y : 0.0f;
+        t_max.z += az ? t_delta.z : 0.0f;
+        cell = make_uint2(0u, 0u);
+        if (idx < s.n_cells) cell = s.cells[idx];
     }
     out = HitRec{closest, best_id, best_ref};
     return best_id != MISS;

@@ -93,7 +93,7 @@ struct HitRec {
 //     detected with per-axis counters of the steps that remain, not by rebuilding cell coordinates,
 //   - the flattened cell index is kept incrementally (wrapping u32, equal to x + y*gx + z*gx*gy mod 2^32),
 //   - "have a hit" is best_id != MISS, not a separate flag,
-//   - a candidate's 48-byte record is loaded while the previous candidate is tested,
+//   - a candidate's 48-byte record is loaded while the previous candidate is tested (loop unrolled by two),
 //   - SKIP: a candidate that the ray already tested in the cell it just left is not tested again. The shader
 //     re-tests it, gets the same t, and that t can neither beat the closest hit under its strict '<' nor turn
 //     a rejection into a hit, so skipping changes nothing. The per-reference mask in q1.w says through which
@@ -174,6 +174,37 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     const uint32_t mx = sx == 1u ? 1u : 2u, my = sy == 1u ? 4u : 8u, mz = sz == 1u ? 16u : 32u;
     uint32_t arrival = 0;
 
+    // One candidate record against the ray (:531-556); returns true when the scan of the list must stop
+    // (any-hit mode and this candidate was accepted).
+    auto test = [&](const float4& c0, const float4& c1, const float4& c2, uint32_t r) -> bool {
+        if (SKIP && (__float_as_uint(c1.w) & arrival)) return false;
+        const uint32_t id = __float_as_uint(c0.w);
+        if (BOXES && id < s.nb) {
+            const float4 b0 = s.box_frame[4 * id], b1 = s.box_frame[4 * id + 1];
+            float t = -1.0f;
+            if (!(__float_as_uint(b0.w) & BOX_CULLED_GRID)) {
+                if (STATS) ctr.box++;
+                t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
+            }
+            if (t >= 0.0f && t < closest) {
+                closest = t;
+                best_id = id;
+                best_ref = MISS;
+                return ANY;
+            }
+        } else {
+            if (STATS && id != REF_INVALID) ctr.tri++;
+            const float t = moller_trumbore<WGSL>(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z), v3(c2.x, c2.y, c2.z));
+            if (t > 0.0f && t < closest && id != REF_INVALID) {
+                closest = t;
+                best_id = id;
+                best_ref = r;
+                return ANY;
+            }
+        }
+        return false;
+    };
+
     // traversal (:520-588)
     uint2 cell = make_uint2(0u, 0u);
     if (idx < s.n_cells) cell = s.cells[idx];  // past the array = empty cell
@@ -189,46 +220,31 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         const bool az = !ax && !ay;
         const uint32_t rem = ax ? rx : (ay ? ry : rz);
         const uint32_t idx_next = idx + (ax ? dix : (ay ? diy : diz));
+        const float t_exit = fminf(fminf(t_max.x, t_max.y), t_max.z);
         const uint32_t n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
         if (n) {
+            // Two records per trip, each loaded while the other is tested, so the record in flight never has
+            // to be copied into the registers of the record under test; one running pointer, so the six loads
+            // of a trip use immediate offsets. The load one past the cell's list stays inside the array
+            // (padded by one record) and its result is not used.
             uint32_t r = cell.x;
-            float4 q0 = s.refs[3 * r], q1 = s.refs[3 * r + 1], q2 = s.refs[3 * r + 2];
-            for (uint32_t j = 0; j < n; ++j, ++r) {
-                const float4 c0 = q0, c1 = q1, c2 = q2;
-                // next record; one past the cell's list is still inside the array (padded by one record)
-                q0 = s.refs[3 * r + 3], q1 = s.refs[3 * r + 4], q2 = s.refs[3 * r + 5];
-                const uint32_t id = __float_as_uint(c0.w);
-                if (SKIP && (__float_as_uint(c1.w) & arrival)) continue;
-                if (BOXES && id < s.nb) {
-                    const float4 b0 = s.box_frame[4 * id], b1 = s.box_frame[4 * id + 1];
-                    float t = -1.0f;
-                    if (!(__float_as_uint(b0.w) & BOX_CULLED_GRID)) {
-                        if (STATS) ctr.box++;
-                        t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
-                    }
-                    if (t >= 0.0f && t < closest) {
-                        closest = t;
-                        best_id = id;
-                        best_ref = MISS;
-                        if (ANY) break;
-                    }
-                } else {
-                    if (STATS && id != REF_INVALID) ctr.tri++;
-                    const float t = moller_trumbore<WGSL>(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z),
-                                                          v3(c2.x, c2.y, c2.z));
-                    if (t > 0.0f && t < closest && id != REF_INVALID) {
-                        closest = t;
-                        best_id = id;
-                        best_ref = r;
-                        if (ANY) break;
-                    }
-                }
+            const uint32_t r_end = r + n;
+            const float4* p = s.refs + 3 * (size_t)r;
+            float4 a0 = p[0], a1 = p[1], a2 = p[2];
+            for (;;) {
+                const float4 b0 = p[3], b1 = p[4], b2 = p[5];
+                if (test(a0, a1, a2, r)) break;
+                if (++r == r_end) break;
+                a0 = p[6], a1 = p[7], a2 = p[8];
+                p += 6;
+                if (test(b0, b1, b2, r)) break;
+                if (++r == r_end) break;
             }
         }
-        if (ANY && best_id != MISS) break;
-        // early-out (:561)
-        if (best_id != MISS && closest < fminf(fminf(t_max.x, t_max.y), t_max.z)) break;
-        if (rem == 0u) break;  // the step would leave the grid
+        // any-hit done, early-out (:561: the hit lies inside this cell), or the step would leave the grid;
+        // plain '|' and '&': short-circuit forms become branches
+        const bool hit = best_id != MISS;
+        if ((ANY & hit) | (hit & (closest < t_exit)) | (rem == 0u)) break;
         rx -= ax ? 1u : 0u;
         ry -= ay ? 1u : 0u;
         rz -= az ? 1u : 0u;

@@ -463,6 +463,106 @@ __device__ inline bool trace_ray_p(const DevScene& s, V3 o, const RayDir& rd, Hi
     return best_id != MISS;
 }
 
+// VARIANT 8: as 7, with the candidate loop unrolled by two (no register rotation between the record being
+// tested and the one in flight), one running record pointer with immediate offsets, and a DDA tail without
+// short-circuit control flow.
+template <bool ANY>
+__device__ inline bool trace_ray_u(const DevScene& s, V3 o, const RayDir& rd, HitRec& out) {
+    float closest = 1e10f;
+    uint32_t best_id = MISS, best_ref = MISS;
+    const V3 d = rd.d, inv = rd.inv;
+    const V3 bmin = v3(s.bmin[0], s.bmin[1], s.bmin[2]), bmax = v3(s.bmax[0], s.bmax[1], s.bmax[2]);
+    const float cs = s.cell_size;
+    V3 pos = o;
+    float t_off = 0.0f;
+    if (pos.x < bmin.x || pos.x > bmax.x || pos.y < bmin.y || pos.y > bmax.y || pos.z < bmin.z || pos.z > bmax.z) {
+        const float t_entry = slab(o, inv, bmin, bmax);
+        if (t_entry < 0.0f) return false;
+        t_off = t_entry + 0.001f;
+        pos = o + d * t_off;
+        const float e = 0.0001f;
+        pos = vmin(vmax(pos, bmin + v3(e, e, e)), bmax - v3(e, e, e));
+    }
+    uint32_t cx, cy, cz;
+    {
+        const V3 rel = pos - bmin;
+        const float ics = s.inv_cell_size;
+        cx = f2u_sat(fmaxf(0.0f, floorf(rel.x * ics)));
+        cy = f2u_sat(fmaxf(0.0f, floorf(rel.y * ics)));
+        cz = f2u_sat(fmaxf(0.0f, floorf(rel.z * ics)));
+    }
+    const uint32_t sx = rd.sx, sy = rd.sy, sz = rd.sz, dix = rd.dix, diy = rd.diy, diz = rd.diz;
+    const V3 cell_world = bmin + v3((float)cx, (float)cy, (float)cz) * cs;
+    const V3 next_b = cell_world + v3(sx == 1u ? cs : 0.0f, sy == 1u ? cs : 0.0f, sz == 1u ? cs : 0.0f);
+    const V3 t_delta = rd.t_delta;
+    V3 t_max = v3(t_off, t_off, t_off) + (next_b - pos) * inv;
+    {
+        const float fl = t_off + 0.00001f;
+        t_max = vmax(t_max, v3(fl, fl, fl));
+    }
+    uint32_t idx = cx + cy * s.gx + cz * s.gx * s.gy;
+    uint32_t rx = sx == 1u ? (cx < s.gx ? s.gx - 1u - cx : 0u) : (cx > s.gx ? 0u : cx);
+    uint32_t ry = sy == 1u ? (cy < s.gy ? s.gy - 1u - cy : 0u) : (cy > s.gy ? 0u : cy);
+    uint32_t rz = sz == 1u ? (cz < s.gz ? s.gz - 1u - cz : 0u) : (cz > s.gz ? 0u : cz);
+    const uint32_t mx = sx == 1u ? 1u : 2u, my = sy == 1u ? 4u : 8u, mz = sz == 1u ? 16u : 32u;
+    uint32_t arrival = 0;
+    uint2 cell = make_uint2(0u, 0u);
+    if (idx < s.n_cells) cell = s.cells[idx];
+    // tests one record; true = stop scanning (any-hit found)
+    auto test = [&](const float4& c0, const float4& c1, const float4& c2, uint32_t r) -> bool {
+        if (!(__float_as_uint(c1.w) & arrival)) {
+            const float t = moller_trumbore<false>(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z), v3(c2.x, c2.y, c2.z));
+            const uint32_t id = __float_as_uint(c0.w);
+            if (t > 0.0f && t < closest && id != REF_INVALID) {
+                closest = t;
+                best_id = id;
+                best_ref = r;
+                return ANY;
+            }
+        }
+        return false;
+    };
+    for (uint32_t i = 0; i < s.max_steps; ++i) {
+        const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
+        const bool ay = !ax && t_max.y < t_max.z;
+        const bool az = !ax && !ay;
+        const uint32_t rem = ax ? rx : (ay ? ry : rz);
+        const uint32_t idx_next = idx + (ax ? dix : (ay ? diy : diz));
+        const float t_exit = fminf(fminf(t_max.x, t_max.y), t_max.z);
+        const uint32_t n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
+        if (n) {
+            uint32_t r = cell.x;
+            const uint32_t r_end = r + n;
+            const float4* p = s.refs + 3 * (size_t)r;
+            float4 a0 = p[0], a1 = p[1], a2 = p[2];
+            for (;;) {
+                const float4 b0 = p[3], b1 = p[4], b2 = p[5];  // one past the list is inside the padded array
+                if (test(a0, a1, a2, r)) break;
+                if (++r == r_end) break;
+                a0 = p[6], a1 = p[7], a2 = p[8];
+                p += 6;
+                if (test(b0, b1, b2, r)) break;
+                if (++r == r_end) break;
+            }
+        }
+        const bool hit = best_id != MISS;
+        const bool stop = (ANY & hit) | (hit & (closest < t_exit)) | (rem == 0u);
+        if (stop) break;
+        rx -= ax ? 1u : 0u;
+        ry -= ay ? 1u : 0u;
+        rz -= az ? 1u : 0u;
+        idx = idx_next;
+        arrival = ax ? mx : (ay ? my : mz);
+        t_max.x += ax ? t_delta.x : 0.0f;
+        t_max.y += ay ? t_delta.y : 0.0f;
+        t_max.z += az ? t_delta.z : 0.0f;
+        cell = make_uint2(0u, 0u);
+        if (idx < s.n_cells) cell = s.cells[idx];
+    }
+    out = HitRec{closest, best_id, best_ref};
+    return best_id != MISS;
+}
+
 // VARIANT 0: the shipped trace_ray
 // VARIANT 5 / 6: body 2 / 3 (trip counters, without / with re-test skipping) + per-wave start/end timestamps (s_memrealtime, 100 MHz) into g_wave_t
 __device__ unsigned long long g_wave_t[2 * 65536];
@@ -502,7 +602,7 @@ __global__ __launch_bounds__(VarCfg<VARIANT>::threads, VarCfg<VARIANT>::min_wave
         if constexpr (BODY == 1) return trace_ray_c<ANY>(s, o, rd, h);
         else if constexpr (BODY == 2) return trace_ray_t<ANY>(s, o, rd, h);
         else if constexpr (BODY == 7) return trace_ray_p<1, ANY>(s, o, rd, h);
-        else if constexpr (BODY == 8) return trace_ray_p<5, ANY>(s, o, rd, h);
+        else if constexpr (BODY == 8) return trace_ray_u<ANY>(s, o, rd, h);
         else if constexpr (BODY == 9) return trace_ray_p<4, ANY>(s, o, rd, h);
         else if constexpr (BODY == 3) return trace_ray_m<ANY>(s, o, rd, h);
         else if constexpr (BODY == 4) return trace_ray_m2<ANY>(s, o, rd, h);

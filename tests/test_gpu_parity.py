@@ -242,6 +242,25 @@ def test_trace_finer_grids(core, ob, rt, car_xyz9):
         check_frame(core, ob, scene, cam, 160, 90, what=f"car cell {cell}")
 
 
+@pytest.mark.parametrize("build_cap,trace_cap", [(8, 8192), (12, 5), (8192, 6)])
+def test_trace_truncated_cell_lists(rt, ob, car_xyz9, build_cap, trace_cap):
+    """Cell lists cut short at build time (overflow drops the highest ids, src/grid.rs:262-283) and / or at trace
+    time (max_objects_per_cell). A triangle dropped from one cell but kept in its neighbour must still be tested
+    in the neighbour: the kernel's skipping of repeated tests may not assume the earlier cell held it."""
+    core = rt.TraceCore(0, rt.default_params(max_objects_per_cell=trace_cap))
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    core.set_scene(None, tris)
+    core.build_grid(max_per_cell=build_cap)
+    scene = ob.Scene(None, tris, max_per_cell=build_cap)
+    cs, idx = core.read_grid_csr()
+    assert np.array_equal(cs, scene.grid.cell_start) and np.array_equal(idx, scene.grid.indices)
+    assert np.diff(cs).max() == min(build_cap, 76)
+    for pos, yaw, pitch in (((200, 200, 300), 3.35, -0.28), ((0, 150, 50), 1.0, -0.4)):
+        cam = rt.Camera(pos, yaw, pitch).to_uniform(0.0, 135.0)
+        check_frame(core, ob, scene, cam, 240, 135, what=f"caps {build_cap}/{trace_cap} from {pos}")
+    core.close()
+
+
 def test_trace_phoenix(core, ob, rt, phoenix_xyz9):
     scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(phoenix_xyz9))
     cam = rt.Camera((-300, 250, 600), 2.7, -0.2).to_uniform(0.0, 180.0)

@@ -20,12 +20,21 @@ thread_local std::string g_create_error;
 
 // ---------------------------------------------------------------- small kernels
 
-__global__ void k_emit_cells(const uint32_t* __restrict__ cell_start, uint32_t n_cells, uint2* __restrict__ cells) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_cells) {
-        uint32_t a = cell_start[c], b = cell_start[c + 1];
-        cells[c] = make_uint2(a, b - a);
+// (first, count) per cell, in the bordered layout the trace kernels walk: a one-cell shell of sentinel records
+// around the gx x gy x gz grid.
+__global__ void k_emit_cells(const uint32_t* __restrict__ cell_start, uint32_t gx, uint32_t gy, uint32_t gz,
+                             uint2* __restrict__ cells) {
+    const uint32_t px = gx + 2, py = gy + 2, pz = gz + 2;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)px * py * pz) return;
+    const uint32_t x = (uint32_t)(p % px), y = (uint32_t)((p / px) % py), z = (uint32_t)(p / ((size_t)px * py));
+    uint2 rec = make_uint2(0u, CELL_SENTINEL);
+    if (x >= 1 && x <= gx && y >= 1 && y <= gy && z >= 1 && z <= gz) {
+        const size_t c = (size_t)(x - 1) + (size_t)(y - 1) * gx + (size_t)(z - 1) * gx * gy;
+        const uint32_t a = cell_start[c], b = cell_start[c + 1];
+        rec = make_uint2(a, b - a);
     }
+    cells[p] = rec;
 }
 
 // One 48-byte record per reference, in cell order.
@@ -159,6 +168,9 @@ DevScene make_scene(const rt_ctx* c) {
     s.gx = c->meta.grid_sizes[RT_GRID_LEVELS - 1][0];
     s.gy = c->meta.grid_sizes[RT_GRID_LEVELS - 1][1];
     s.gz = c->meta.grid_sizes[RT_GRID_LEVELS - 1][2];
+    s.px = s.gx + 2;
+    s.pxy = s.px * (s.gy + 2);
+    s.n_bordered = s.pxy * (s.gz + 2);
     s.max_per_cell = c->params.max_objects_per_cell;
     s.max_steps = c->params.max_dda_steps;
     s.moving_start = s.nb >= c->params.moving_box_count ? s.nb - c->params.moving_box_count : 0u;
@@ -173,7 +185,8 @@ DevScene make_scene(const rt_ctx* c) {
 
 // Per-frame constants the shader evaluates per pixel; evaluated once here with the host libm.
 DevFrame make_frame(const rt_ctx* c, const CameraUniform* cam, uint32_t w, uint32_t h) {
-    const uint32_t gx = c->meta.grid_sizes[RT_GRID_LEVELS - 1][0], gy = c->meta.grid_sizes[RT_GRID_LEVELS - 1][1];
+    const uint32_t px = c->meta.grid_sizes[RT_GRID_LEVELS - 1][0] + 2;
+    const uint32_t pxy = px * (c->meta.grid_sizes[RT_GRID_LEVELS - 1][1] + 2);
     DevFrame f;
     memset(&f, 0, sizeof(f));
     if (cam) {
@@ -186,8 +199,8 @@ DevFrame make_frame(const rt_ctx* c, const CameraUniform* cam, uint32_t w, uint3
     }
     f.fov_scale = tanf(c->params.fov);                       // raytracer_unified.wgsl:643
     const V3 sd = neg(normalize(ld3(c->params.light_direction)));  // raytracer_unified.wgsl:599-600
-    f.shadow = c->params.wgsl_compat ? make_ray_dir<true>(sd, c->meta.finest_cell_size, gx, gy)
-                                     : make_ray_dir<false>(sd, c->meta.finest_cell_size, gx, gy);
+    f.shadow = c->params.wgsl_compat ? make_ray_dir<true>(sd, c->meta.finest_cell_size, px, pxy)
+                                     : make_ray_dir<false>(sd, c->meta.finest_cell_size, px, pxy);
     f.shadow_offset = c->params.shadow_offset;
     f.width = w;
     f.height = h;
@@ -295,10 +308,15 @@ int stage_in(rt_ctx* c, DevBuf& buf, const void* src, size_t bytes, const void**
 namespace rt {
 
 int emit_refs_from_csr(rt_ctx* c) {
-    RT_HIP(c, c->cells.reserve((size_t)c->n_cells * sizeof(uint2)));
+    const uint32_t* g = c->meta.grid_sizes[RT_GRID_LEVELS - 1];
+    const unsigned long long bordered = (g[0] + 2ull) * (g[1] + 2ull) * (g[2] + 2ull);
+    if (bordered > 0xFFFFFFFFull)
+        return fail(c, RT_ERR_LIMIT, "grid of %u x %u x %u cells: the bordered cell array has %llu entries (max 2^32-1)",
+                    g[0], g[1], g[2], bordered);
+    RT_HIP(c, c->cells.reserve((size_t)bordered * sizeof(uint2)));
     RT_HIP(c, c->refs.reserve(((size_t)c->n_refs * 3 + 3) * sizeof(float4)));
-    hipLaunchKernelGGL(k_emit_cells, dim3((c->n_cells + 255) / 256), dim3(256), 0, c->stream,
-                       c->cell_start.as<uint32_t>(), c->n_cells, c->cells.as<uint2>());
+    hipLaunchKernelGGL(k_emit_cells, dim3((unsigned)((bordered + 255) / 256)), dim3(256), 0, c->stream,
+                       c->cell_start.as<uint32_t>(), g[0], g[1], g[2], c->cells.as<uint2>());
     RT_HIP(c, hipGetLastError());
     if (c->n_refs) {
         hipLaunchKernelGGL(k_emit_refs, dim3((c->n_refs + 255) / 256), dim3(256), 0, c->stream,
@@ -788,23 +806,7 @@ extern "C" int rt_intersect_tri_pairs(rt_ctx* c, const float* origins, const flo
 }
 
 #ifdef RT_EXPERIMENTS
-// development only: read and clear the per-wave trip counters of the instrumented variant
-extern "C" int rt_dbg_trips(rt_ctx* c, unsigned long long* out8) {
-    if (int r = use(c)) return r;
-    RT_HIP(c, hipStreamSynchronize(c->stream));
-    RT_HIP(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(rt::g_trip), 8 * sizeof(unsigned long long)));
-    unsigned long long z[8] = {0};
-    RT_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(rt::g_trip), z, sizeof(z)));
-    return RT_OK;
-}
-extern "C" int rt_dbg_wave_trips(rt_ctx* c, unsigned int* out, size_t n) {
-    if (int r = use(c)) return r;
-    RT_HIP(c, hipStreamSynchronize(c->stream));
-    RT_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_wave_trips), n * sizeof(unsigned int)));
-    std::vector<unsigned int> z(n, 0u);
-    RT_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(rt::g_wave_trips), z.data(), n * sizeof(unsigned int)));
-    return RT_OK;
-}
+// development only: per-wave timestamps of the instrumented variant
 extern "C" int rt_dbg_wave_times(rt_ctx* c, unsigned long long* out, size_t n) {
     if (int r = use(c)) return r;
     RT_HIP(c, hipStreamSynchronize(c->stream));

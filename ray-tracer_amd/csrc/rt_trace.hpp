@@ -5,7 +5,8 @@
 // (src/raytracer_unified.wgsl:430-588 trace_ray, :625-653 ray generation).
 //
 // Data layout in HBM (built by rt_build.hip / the gather kernels in rt_api.hip):
-//   cells[c]      uint2 (first ref, ref count) per fine grid cell, c = x + y*gx + z*gx*gy
+//   cells[c]      uint2 (first ref, ref count) per fine grid cell, with a one-cell border on every side whose
+//                 count is CELL_SENTINEL: c = (x+1) + (y+1)*px + (z+1)*px*py, px = gx+2, py = gy+2
 //   refs[3*r..]   one 48-byte record per (cell, object) reference, stored in cell order so a
 //                 cell's candidates are contiguous:  (v0.xyz, id bits) (e1.xyz, 0) (e2.xyz, 0)
 //                 for a triangle, (0,0,0, id bits) for a box (box data is per frame, below); the spare word of
@@ -21,6 +22,7 @@ namespace rt {
 
 constexpr uint32_t MISS = 0xFFFFFFFFu;
 constexpr uint32_t REF_INVALID = 0xFFFFFFFEu;  // reference to a triangle index >= num_triangles: skipped
+constexpr uint32_t CELL_SENTINEL = 0xFFFFFFFFu;  // count of a border cell: the ray has left the grid
 constexpr uint32_t BOX_CULLED_GRID = 1u;       // LOD cull outcome when met through a grid cell
 constexpr uint32_t BOX_CULLED_PREPASS = 2u;    // LOD cull outcome in the moving-box pre-pass
 
@@ -31,6 +33,8 @@ struct DevScene {
     const float4* box_frame;
     uint32_t nb, nt, n_cells, n_refs;
     uint32_t gx, gy, gz;
+    uint32_t px, pxy;  // strides of the bordered cell array: gx + 2 and (gx + 2) * (gy + 2)
+    uint32_t n_bordered;  // its length: (gx + 2) * (gy + 2) * (gz + 2)
     uint32_t max_per_cell, max_steps, moving_start;
     float bmin[3], bmax[3];
     float cell_size;
@@ -46,8 +50,9 @@ struct RayDir {
     uint32_t dix, diy, diz; // change of the flattened cell index for a step along each axis
 };
 
+// px, pxy: strides of the bordered cell array.
 template <bool WGSL>
-__host__ __device__ inline RayDir make_ray_dir(V3 d, float cell_size, uint32_t gx, uint32_t gy) {
+__host__ __device__ inline RayDir make_ray_dir(V3 d, float cell_size, uint32_t px, uint32_t pxy) {
     RayDir r;
     r.d = d;
     r.inv = v3(safe_inv<WGSL>(d.x), safe_inv<WGSL>(d.y), safe_inv<WGSL>(d.z));
@@ -56,8 +61,8 @@ __host__ __device__ inline RayDir make_ray_dir(V3 d, float cell_size, uint32_t g
     r.sy = d.y >= 0.0f ? 1u : 0xFFFFFFFFu;
     r.sz = d.z >= 0.0f ? 1u : 0xFFFFFFFFu;
     r.dix = r.sx;
-    r.diy = r.sy * gx;
-    r.diz = r.sz * (gx * gy);
+    r.diy = r.sy * px;
+    r.diz = r.sz * pxy;
     return r;
 }
 
@@ -84,14 +89,44 @@ struct HitRec {
     uint32_t ref;  // index of the winning reference record (triangles) - used to rebuild the normal
 };
 
+// Structured buffer loads (buffer_load_dwordx{2,4} ... idxen): the address is base + index * stride + constant,
+// formed by the memory unit from a record index in one VGPR and a descriptor in four SGPRs, so the traversal
+// spends no vector instructions on 64-bit address arithmetic, and the compiler cannot split or re-shape the
+// loads the way it does plain pointer loads. An index >= num_records reads as zeros.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ v4i llvm_struct_buffer_load_v4i32(v4i rsrc, int vindex, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.struct.buffer.load.v4i32");
+__device__ v2i llvm_struct_buffer_load_v2i32(v4i rsrc, int vindex, int voffset, int soffset, int aux) __asm(
+    "llvm.amdgcn.struct.buffer.load.v2i32");
+
+__device__ inline v4i make_rsrc(const void* base, uint32_t stride, uint32_t num_records) {
+    const uint64_t b = (uint64_t)base;
+    v4i r;
+    r.x = (int)(uint32_t)b;
+    r.y = (int)(((uint32_t)(b >> 32) & 0xFFFFu) | (stride << 16));
+    r.z = (int)num_records;
+    r.w = 0x00020000;  // untyped 32-bit data, no swizzle
+    return r;
+}
+template <int BYTE_OFFSET>
+__device__ inline float4 buf_load16(v4i rsrc, uint32_t index) {
+    const v4i v = llvm_struct_buffer_load_v4i32(rsrc, (int)index, BYTE_OFFSET, 0, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+__device__ inline uint2 buf_load8(v4i rsrc, uint32_t index) {
+    const v2i v = llvm_struct_buffer_load_v2i32(rsrc, (int)index, 0, 0, 0);
+    return make_uint2((uint32_t)v.x, (uint32_t)v.y);
+}
+
 // One ray through the grid; mirrors raytracer_unified.wgsl:430-588.
 //
 // Per-wave cost on gfx950 is set by instruction issue and by the length of the dependent chain of the
 // heaviest wave (a few 8x8 pixel blocks over the model's densest cells run 10-30x the average number of
 // candidate tests and finish last), not by memory bandwidth: the scene is cache resident. So:
-//   - the DDA step is branch-free (selects instead of an if / else-if / else ladder) and leaving the grid is
-//     detected with per-axis counters of the steps that remain, not by rebuilding cell coordinates,
-//   - the flattened cell index is kept incrementally (wrapping u32, equal to x + y*gx + z*gx*gy mod 2^32),
+//   - the DDA step is branch-free (selects instead of an if / else-if / else ladder), the flattened cell index
+//     is kept incrementally and leaving the grid is detected by a sentinel border around the cell array, not by
+//     rebuilding and range-checking cell coordinates,
 //   - "have a hit" is best_id != MISS, not a separate flag,
 //   - a candidate's 48-byte record is loaded while the previous candidate is tested (loop unrolled by two),
 //   - SKIP: a candidate that the ray already tested in the cell it just left is not tested again. The shader
@@ -102,12 +137,15 @@ struct HitRec {
 // ANY: stop at the first accepted intersection. BOXES: scene has boxes (pre-pass + box candidates).
 // STATS: count what the REFERENCE algorithm does (no skipping), for parity of the counters and for the
 // algorithmic byte count. Returns true on a hit.
-template <bool WGSL, bool ANY, bool STATS, bool BOXES>
+// X: development switch (0 in every shipped instantiation).
+template <bool WGSL, bool ANY, bool STATS, bool BOXES, int X = 0>
 __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitRec& out, Counters& ctr) {
     constexpr bool SKIP = !STATS;
     float closest = 1e10f;
     uint32_t best_id = MISS, best_ref = MISS;
     const V3 d = rd.d, inv = rd.inv;
+    const v4i refs = make_rsrc(s.refs, 48, s.n_refs + 1);
+    const v4i cells = make_rsrc(s.cells, 8, s.n_bordered);
     if (STATS) ctr.steps = 0;
 
     // moving boxes are tested directly, before the grid (:442-461)
@@ -163,13 +201,6 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         const float fl = t_off + 0.00001f;
         t_max = vmax(t_max, v3(fl, fl, fl));
     }
-    uint32_t idx = cx + cy * s.gx + cz * s.gx * s.gy;  // get_fine_index (:406-409), wrapping
-    // Steps that can still be taken along each axis before the shader's test (next < 0 || next >= g, :568-583)
-    // ends the traversal. A start cell outside the grid (only possible for an origin on the far bounds) can take
-    // none in the + direction; in the - direction it can step only if that lands inside (c - 1 < g).
-    uint32_t rx = sx == 1u ? (cx < s.gx ? s.gx - 1u - cx : 0u) : (cx > s.gx ? 0u : cx);
-    uint32_t ry = sy == 1u ? (cy < s.gy ? s.gy - 1u - cy : 0u) : (cy > s.gy ? 0u : cy);
-    uint32_t rz = sz == 1u ? (cz < s.gz ? s.gz - 1u - cz : 0u) : (cz > s.gz ? 0u : cz);
     // face through which the current cell was entered, as a bit of the re-test mask (0 = start cell)
     const uint32_t mx = sx == 1u ? 1u : 2u, my = sy == 1u ? 4u : 8u, mz = sz == 1u ? 16u : 32u;
     uint32_t arrival = 0;
@@ -205,56 +236,96 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         return false;
     };
 
-    // traversal (:520-588)
-    uint2 cell = make_uint2(0u, 0u);
-    if (idx < s.n_cells) cell = s.cells[idx];  // past the array = empty cell
+    // A cell's candidate list. Two records per trip, each loaded while the other is tested, so the record in
+    // flight never has to be copied into the registers of the record under test. The load one past the list
+    // stays inside the array (padded by one record) and its result is not used.
+    auto scan = [&](uint32_t r, uint32_t n) {
+        const uint32_t r_end = r + n;
+        float4 a0 = buf_load16<0>(refs, r), a1 = buf_load16<16>(refs, r), a2 = buf_load16<32>(refs, r);
+        for (;;) {
+            const float4 b0 = buf_load16<0>(refs, r + 1), b1 = buf_load16<16>(refs, r + 1), b2 = buf_load16<32>(refs, r + 1);
+            if (test(a0, a1, a2, r)) break;
+            if (++r == r_end) break;
+            a0 = buf_load16<0>(refs, r + 1), a1 = buf_load16<16>(refs, r + 1), a2 = buf_load16<32>(refs, r + 1);
+            if (test(b0, b1, b2, r)) break;
+            if (++r == r_end) break;
+        }
+    };
+
+    if (cx >= s.gx || cy >= s.gy || cz >= s.gz) {
+        // Start cell outside the grid: an origin exactly on a far bound (or metadata that disagrees with the
+        // bounds). The shader carries on with the out-of-range coordinates: the flattened index
+        // x + y*gx + z*gx*gy (:406-409) then names some other cell, or none, until a step brings the ray inside,
+        // and a step whose target is outside ends the traversal (:568-583). Rare, so it is restated literally.
+        for (uint32_t i = 0; i < s.max_steps; ++i) {
+            if (STATS) {
+                ctr.steps++;
+                ctr.cells++;
+            }
+            const uint32_t fi = cx + cy * s.gx + cz * s.gx * s.gy;  // wrapping, as in the shader
+            uint32_t n = 0, first = 0;
+            if (fi < s.n_cells) {
+                const uint32_t x = fi % s.gx, y = (fi / s.gx) % s.gy, z = fi / (s.gx * s.gy);
+                const uint2 cell = buf_load8(cells, (x + 1u) + (y + 1u) * s.px + (z + 1u) * s.pxy);
+                first = cell.x;
+                n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
+            }
+            if (n) scan(first, n);
+            const bool hit = best_id != MISS;
+            if (ANY && hit) break;
+            if (hit && closest < fminf(fminf(t_max.x, t_max.y), t_max.z)) break;
+            if (t_max.x < t_max.y && t_max.x < t_max.z) {
+                const uint32_t next = cx + sx;
+                if (next >= s.gx) break;
+                cx = next;
+                t_max.x += t_delta.x;
+            } else if (t_max.y < t_max.z) {
+                const uint32_t next = cy + sy;
+                if (next >= s.gy) break;
+                cy = next;
+                t_max.y += t_delta.y;
+            } else {
+                const uint32_t next = cz + sz;
+                if (next >= s.gz) break;
+                cz = next;
+                t_max.z += t_delta.z;
+            }
+        }
+        out = HitRec{closest, best_id, best_ref};
+        return best_id != MISS;
+    }
+
+    // traversal (:520-588). The cell array has a one-cell border of sentinel records on every side, so "the
+    // step leaves the grid" (:568-583) is "the cell just fetched is a sentinel": no coordinates, no per-axis
+    // counters and no range check on the index.
+    uint32_t idx = (cx + 1u) + (cy + 1u) * s.px + (cz + 1u) * s.pxy;
+    uint2 cell = buf_load8(cells, idx);
     for (uint32_t i = 0; i < s.max_steps; ++i) {
+        // The step this iteration ends with (:566-587: x if tx < ty and tx < tz, else y if ty < tz, else z)
+        // depends on t_max only; deciding it here keeps it off the candidate loop's exit path and gives the
+        // cell record fetched at the end of the previous iteration time to arrive.
+        const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
+        const bool ay = !ax && t_max.y < t_max.z;
+        const bool az = !ax && !ay;
+        const uint32_t idx_next = idx + (ax ? dix : (ay ? diy : diz));
+        const float t_exit = fminf(fminf(t_max.x, t_max.y), t_max.z);
+        if (cell.y == CELL_SENTINEL) break;  // the previous step left the grid
         if (STATS) {
             ctr.steps++;
             ctr.cells++;
         }
-        // The step this iteration ends with (:566-587: x if tx < ty and tx < tz, else y if ty < tz, else z)
-        // depends on t_max only; deciding it before the candidate loop keeps it off the loop's exit path.
-        const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
-        const bool ay = !ax && t_max.y < t_max.z;
-        const bool az = !ax && !ay;
-        const uint32_t rem = ax ? rx : (ay ? ry : rz);
-        const uint32_t idx_next = idx + (ax ? dix : (ay ? diy : diz));
-        const float t_exit = fminf(fminf(t_max.x, t_max.y), t_max.z);
         const uint32_t n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
-        if (n) {
-            // Two records per trip, each loaded while the other is tested, so the record in flight never has
-            // to be copied into the registers of the record under test; one running pointer, so the six loads
-            // of a trip use immediate offsets. The load one past the cell's list stays inside the array
-            // (padded by one record) and its result is not used.
-            uint32_t r = cell.x;
-            const uint32_t r_end = r + n;
-            const float4* p = s.refs + 3 * (size_t)r;
-            float4 a0 = p[0], a1 = p[1], a2 = p[2];
-            for (;;) {
-                const float4 b0 = p[3], b1 = p[4], b2 = p[5];
-                if (test(a0, a1, a2, r)) break;
-                if (++r == r_end) break;
-                a0 = p[6], a1 = p[7], a2 = p[8];
-                p += 6;
-                if (test(b0, b1, b2, r)) break;
-                if (++r == r_end) break;
-            }
-        }
-        // any-hit done, early-out (:561: the hit lies inside this cell), or the step would leave the grid;
-        // plain '|' and '&': short-circuit forms become branches
+        if (n) scan(cell.x, n);
+        // any-hit done, or early-out (:561: the hit lies inside this cell); plain '|' and '&': short-circuit
+        // forms become branches
         const bool hit = best_id != MISS;
-        if ((ANY & hit) | (hit & (closest < t_exit)) | (rem == 0u)) break;
-        rx -= ax ? 1u : 0u;
-        ry -= ay ? 1u : 0u;
-        rz -= az ? 1u : 0u;
+        if ((ANY & hit) | (hit & (closest < t_exit))) break;
         idx = idx_next;
         arrival = ax ? mx : (ay ? my : mz);
         t_max.x += ax ? t_delta.x : 0.0f;
         t_max.y += ay ? t_delta.y : 0.0f;
         t_max.z += az ? t_delta.z : 0.0f;
-        cell = make_uint2(0u, 0u);
-        if (idx < s.n_cells) cell = s.cells[idx];
+        cell = buf_load8(cells, idx);
     }
     out = HitRec{closest, best_id, best_ref};
     return best_id != MISS;
@@ -325,7 +396,7 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
     if (live) {
         const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         const V3 d = primary_dir(f, px, py);
-        const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.gx, s.gy);
+        const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
         HitRec h;
         n_rays++;
         if (trace_ray<WGSL, false, STATS, BOXES>(s, o, rd, h, ctr)) {
@@ -365,7 +436,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __r
     if (i < n) {
         HitRec h;
         n_rays = 1;
-        const RayDir rd = make_ray_dir<WGSL>(ld3(dirs + 3 * (size_t)i), s.cell_size, s.gx, s.gy);
+        const RayDir rd = make_ray_dir<WGSL>(ld3(dirs + 3 * (size_t)i), s.cell_size, s.px, s.pxy);
         bool hit = trace_ray<WGSL, ANY, STATS, BOXES>(s, ld3(origins + 3 * (size_t)i), rd, h, ctr);
         n_hit = hit ? 1 : 0;
         out[i] = hit ? make_uint2(h.id, __float_as_uint(h.t)) : make_uint2(MISS, 0u);
@@ -381,7 +452,7 @@ __global__ void k_debug_pixel(DevScene s, DevFrame f, uint32_t px, uint32_t py, 
     const V3 d = primary_dir(f, px, py);
     HitRec h;
     Counters ctr{0, 0, 0, 0};
-    const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.gx, s.gy);
+    const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
     const bool hit = trace_ray<WGSL, false, true, true>(s, o, rd, h, ctr);
     for (int k = 0; k < 20; ++k) info20[k] = 0.0f;
     info20[0] = o.x, info20[1] = o.y, info20[2] = o.z;

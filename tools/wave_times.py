@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development tool: per-wave start/end times of one launch of the headline frame (variant 5)."""
+"""Development tool: per-wave start/end times of one launch of the headline frame (variant 30 = shipped body with timestamps)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,16 +13,12 @@ core.set_scene(None, rt.triangles_from_xyz9(np.load(os.path.join(ROOT, "tests/go
 core.build_grid()
 cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
 p = torch.empty((W * H, 2), dtype=torch.int32, device="cuda"); s = torch.empty_like(p)
-os.environ["RT_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "5"
+os.environ["RT_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "30"
 nw = (W // 8) * (H // 8)
 L = _lib.load()
-trips = np.zeros(4 * nw, np.uint32)
 core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
-L.rt_dbg_wave_trips(core._h, trips.ctypes.data_as(C.c_void_p), C.c_size_t(4 * nw))
 core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
 core.sync()
-L.rt_dbg_wave_trips(core._h, trips.ctypes.data_as(C.c_void_p), C.c_size_t(4 * nw))
-trips = trips.reshape(nw, 4)
 buf = np.zeros(2 * nw, np.uint64)
 _lib.load().rt_dbg_wave_times(core._h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(2 * nw))
 t0, t1 = buf[0::2].astype(np.int64), buf[1::2].astype(np.int64)
@@ -42,13 +38,3 @@ g = dur.reshape(H // 16, 2, W // 16, 2) if False else None
 order = np.argsort(-dur)[:10]
 print("longest waves (global wave id, start, dur):", [(int(i), round(float(start[i]),1), round(float(dur[i]),1)) for i in order])
 
-if trips.sum() == 0:
-    sys.exit(0)
-tot = trips.sum(axis=1)
-print("per-wave trips (pDDA, pMT, sDDA, sMT): mean", trips.mean(axis=0).round(1), "max", trips.max(axis=0))
-for i in order:
-    print(f"  wave {int(i)}: dur {dur[i]:.1f} us trips {trips[i].tolist()}")
-A = np.stack([trips[:, 0] + trips[:, 2], trips[:, 1] + trips[:, 3], np.ones(nw)], axis=1).astype(np.float64)
-coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
-print(f"least squares: dur ~ {coef[0]:.3f} us per DDA trip + {coef[1]:.3f} us per MT trip + {coef[2]:.2f} us")
-print("share of total wave-time: DDA", (coef[0] * A[:, 0].sum()) / dur.sum(), "MT", (coef[1] * A[:, 1].sum()) / dur.sum())

@@ -412,6 +412,36 @@ def test_trace_rays_degenerate_directions(core, ob, car_xyz9):
         assert_hits_equal(core.trace_rays(o, d, any_hit=any_hit), want, f"degenerate any={any_hit}")
 
 
+def test_trace_rays_from_the_far_bounds(core, ob):
+    """Origins exactly on the far faces, edges and corner of a grid whose extent is a whole number of cells: the
+    start cell index equals the grid dimension, the shader keeps going with it (its flattened index then names
+    a cell of the next row or slab, raytracer_unified.wgsl:406-409) and only a step back inside, or out, ends that."""
+    rng = np.random.default_rng(21)
+    v = rng.uniform(2.0, 62.0, (600, 1, 3)) + rng.uniform(-6.0, 6.0, (600, 3, 3))
+    tris = ob.triangles_from_xyz9(np.clip(v, 0.5, 63.5).reshape(-1, 9).astype(np.float32))
+    grid = ob.Grid(None, tris, cell_size=16.0)
+    assert grid.meta.fine_dims == (5, 5, 5) and tuple(grid.meta.bounds_min) == (-0.5, -0.5, -0.5)
+    grid.meta.bounds_max[:] = (79.5, 79.5, 79.5)  # exactly five cells of 16 from -0.5
+    scene = ob.Scene(None, tris, grid=grid)
+    core.set_scene(None, tris)
+    core.set_grid_csr(grid.meta, grid.cell_start, grid.indices)
+    n = 3000
+    o = rng.uniform(0.0, 79.0, (n, 3)).astype(np.float32)
+    on = rng.integers(1, 8, n)  # bit k set: coordinate k sits on the far bound
+    for k in range(3):
+        o[(on >> k) & 1 == 1, k] = 79.5
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    slide = rng.random(n) < 0.3  # slide along a face: zero / signed-zero / tiny component on a far axis
+    for k in range(3):
+        m = slide & ((on >> k) & 1 == 1)
+        d[m, k] = rng.choice(np.array([0.0, -0.0, 1e-9, -1e-9], np.float32), m.sum())
+    for any_hit in (False, True):
+        want, st = ob.trace_rays(scene, o, d, any_hit=any_hit)
+        assert_hits_equal(core.trace_rays(o, d, any_hit=any_hit), want, f"far bounds any={any_hit}")
+    assert (want["id"] != ob.MISS).sum() > 100
+
+
 # ------------------------------------------------------------------------------ shards, device buffers, full size
 
 def test_shards_match_oracle_and_assemble(core, ob, rt, car_xyz9):

@@ -131,7 +131,10 @@ __global__ void k_tri_pairs(const float* __restrict__ o, const float* __restrict
     uint32_t r = (uint32_t)(i / n_prims), p = (uint32_t)(i % n_prims);
     const float* v = v012 + 9 * (size_t)p;
     V3 v0 = ld3(v);
-    out[i] = moller_trumbore<WGSL>(ld3(o + 3 * (size_t)r), ld3(d + 3 * (size_t)r), v0, ld3(v + 3) - v0, ld3(v + 6) - v0);
+    const V3 e1 = ld3(v + 3) - v0, e2 = ld3(v + 6) - v0;
+    // the form the trace kernels use (packed two-lane arithmetic), so this entry point checks it pair by pair
+    out[i] = moller_trumbore_pk<WGSL>(make_ray_pk(ld3(o + 3 * (size_t)r), ld3(d + 3 * (size_t)r)), make_float4(v0.x, v0.y, v0.z, 0.f),
+                                      make_float4(e1.x, e1.y, e1.z, 0.f), make_float4(e2.x, e2.y, e2.z, 0.f));
 }
 
 __global__ void k_assemble(const uint2* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w,

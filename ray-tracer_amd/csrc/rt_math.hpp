@@ -112,4 +112,59 @@ __host__ __device__ inline float moller_trumbore(V3 o, V3 d, V3 v0, V3 e1, V3 e2
     return t;
 }
 
+#if defined(__HIPCC__)
+// The same test written for the packed two-lane f32 instructions of gfx950 (v_pk_mul_f32, v_pk_add_f32), which run
+// at the rate of the one-lane forms. Every product and sum below is one of the reference's, with the same operands
+// and the same single rounding; only (a) operands of commutative products are swapped, and (b) the middle
+// component of each cross product is carried negated (hy_n = -h.y, qy_n = -q.y) and subtracted where the reference
+// adds it - x - y and x + (-y), and a - b and -(b - a), are the same IEEE operation - so the results carry identical
+// bits. Pairs are (x, y) of each record quad, which is where a 16-byte load puts them.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct RayPk {
+    f2 dxy, oxy;
+    float dz, oz;
+};
+__device__ inline RayPk make_ray_pk(V3 o, V3 d) { return RayPk{f2{d.x, d.y}, f2{o.x, o.y}, d.z, o.z}; }
+
+template <bool WGSL>
+__device__ inline float moller_trumbore_pk(const RayPk& r, float4 c0, float4 c1, float4 c2) {
+    const float eps = WGSL ? 0.00001f : 1e-6f;
+    const f2 v0xy = {c0.x, c0.y}, e1xy = {c1.x, c1.y}, e2xy = {c2.x, c2.y};
+    const f2 dyx = __builtin_shufflevector(r.dxy, r.dxy, 1, 0);
+    // h = d x e2: (h.x, -h.y) = e2.z * (d.y, d.x) - d.z * (e2.y, e2.x);  h.z = d.x*e2.y - e2.x*d.y
+    const f2 hA = dyx * c2.z;
+    const f2 hB = __builtin_shufflevector(e2xy, e2xy, 1, 0) * r.dz;
+    const f2 hxny = hA - hB;
+    const f2 hC = e2xy * dyx;
+    const float hz = hC.y - hC.x;
+    // a = (e1.x*h.x + e1.y*h.y) + e1.z*h.z
+    const f2 aD = e1xy * hxny;
+    const float a = (aD.x - aD.y) + c1.z * hz;
+    const float f = 1.0f / a;
+    // s = o - v0;  u = f * ((s.x*h.x + s.y*h.y) + s.z*h.z)
+    const f2 sxy = r.oxy - v0xy;
+    const float sz = r.oz - c0.z;
+    const f2 uE = sxy * hxny;
+    const float u = f * ((uE.x - uE.y) + sz * hz);
+    float t = -1.0f;
+    if (!(fabsf(a) < eps) && !(u < 0.0f || u > 1.0f)) {
+        // q = s x e1: (q.x, -q.y) = e1.z * (s.y, s.x) - s.z * (e1.y, e1.x);  q.z = s.x*e1.y - e1.x*s.y
+        const f2 syx = __builtin_shufflevector(sxy, sxy, 1, 0);
+        const f2 qA = syx * c1.z;
+        const f2 qB = __builtin_shufflevector(e1xy, e1xy, 1, 0) * sz;
+        const f2 qxny = qA - qB;
+        const f2 qC = e1xy * syx;
+        const float qz = qC.y - qC.x;
+        const f2 vG = r.dxy * qxny;
+        const float v = f * ((vG.x - vG.y) + r.dz * qz);
+        const f2 tH = e2xy * qxny;
+        const float tt = f * ((tH.x - tH.y) + c2.z * qz);
+        const bool t_ok = WGSL ? (tt > eps) : !(tt < eps);
+        if (!(v < 0.0f || u + v > 1.0f) && t_ok) t = tt;
+    }
+    return t;
+}
+#endif
+
 }  // namespace rt

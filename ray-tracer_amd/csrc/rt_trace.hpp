@@ -144,6 +144,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     float closest = 1e10f;
     uint32_t best_id = MISS, best_ref = MISS;
     const V3 d = rd.d, inv = rd.inv;
+    const RayPk rp = make_ray_pk(o, d);
     const v4i refs = make_rsrc(s.refs, 48, s.n_refs + 1);
     const v4i cells = make_rsrc(s.cells, 8, s.n_bordered);
     if (STATS) ctr.steps = 0;
@@ -225,7 +226,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             }
         } else {
             if (STATS && id != REF_INVALID) ctr.tri++;
-            const float t = moller_trumbore<WGSL>(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z), v3(c2.x, c2.y, c2.z));
+            const float t = moller_trumbore_pk<WGSL>(rp, c0, c1, c2);
             if (t > 0.0f && t < closest && id != REF_INVALID) {
                 closest = t;
                 best_id = id;

@@ -197,7 +197,9 @@ int rt_set_collect_stats(rt_ctx* ctx, int enabled);
 /* GPU counterparts of math::intersect_aabb (src/math/ray.rs:3-36) and
  * moller_trumbore_intersect (src/core/triangle_intersection.rs:31-82) evaluated for
  * every (ray, primitive) pair, the shape of the criterion loops
- * (benches/bounding_volumes.rs:162-175). All pointers host.
+ * (benches/bounding_volumes.rs:162-175). Pointers are all host memory (copied in and out, the
+ * call returns when out_t is complete) or all device memory (runs in place, asynchronously on
+ * the context's stream).
  * out_t[r*n_prims + p]: slab result (-1 on miss) / triangle t (-1 on miss). */
 int rt_intersect_aabb_pairs(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n_rays,
                             const float* box_min, const float* box_max, uint32_t n_prims, float* out_t);

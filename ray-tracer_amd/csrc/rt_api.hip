@@ -408,7 +408,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->tri_n,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
-                      &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->out_p,     &c->out_s,
+                      &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->b_obj_n, &c->b_obj_off, &c->b_obj_sum, &c->out_p,     &c->out_s,
                       &c->in_o,      &c->in_d,      &c->stats,      &c->misc};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -762,23 +762,33 @@ extern "C" int rt_intersect_aabb_pairs(rt_ctx* c, const float* origins, const fl
     if (n == 0) return RT_OK;
     if (!origins || !dirs || !box_min || !box_max || !out_t) return fail(c, RT_ERR_INVALID, "rt_intersect_aabb_pairs: NULL argument");
     if (n > 0x7FFFFFFFull * 256) return fail(c, RT_ERR_LIMIT, "rt_intersect_aabb_pairs: too many pairs");
+    // all arguments in device memory: run in place on the context's stream, no copies, no host synchronisation
+    const bool dev = is_device_ptr(out_t);
+    if (dev != is_device_ptr(origins) || dev != is_device_ptr(dirs) || dev != is_device_ptr(box_min) || dev != is_device_ptr(box_max))
+        return fail(c, RT_ERR_INVALID, "rt_intersect_aabb_pairs: arguments must be all host or all device memory");
     const size_t rb = (size_t)n_rays * 12, pb = (size_t)n_prims * 12;
-    RT_HIP(c, c->misc.reserve(2 * rb + 2 * pb + n * sizeof(float) + 64));
-    char* base = c->misc.as<char>();
-    float *d_o = (float*)base, *d_d = (float*)(base + rb), *d_mn = (float*)(base + 2 * rb),
-          *d_mx = (float*)(base + 2 * rb + pb), *d_out = (float*)(base + 2 * rb + 2 * pb);
-    RT_HIP(c, hipMemcpyAsync(d_o, origins, rb, hipMemcpyHostToDevice, c->stream));
-    RT_HIP(c, hipMemcpyAsync(d_d, dirs, rb, hipMemcpyHostToDevice, c->stream));
-    RT_HIP(c, hipMemcpyAsync(d_mn, box_min, pb, hipMemcpyHostToDevice, c->stream));
-    RT_HIP(c, hipMemcpyAsync(d_mx, box_max, pb, hipMemcpyHostToDevice, c->stream));
+    const float *d_o = origins, *d_d = dirs, *d_mn = box_min, *d_mx = box_max;
+    float* d_out = out_t;
+    if (!dev) {
+        RT_HIP(c, c->misc.reserve(2 * rb + 2 * pb + n * sizeof(float) + 64));
+        char* base = c->misc.as<char>();
+        d_o = (float*)base, d_d = (float*)(base + rb), d_mn = (float*)(base + 2 * rb), d_mx = (float*)(base + 2 * rb + pb);
+        d_out = (float*)(base + 2 * rb + 2 * pb);
+        RT_HIP(c, hipMemcpyAsync((void*)d_o, origins, rb, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync((void*)d_d, dirs, rb, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync((void*)d_mn, box_min, pb, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync((void*)d_mx, box_max, pb, hipMemcpyHostToDevice, c->stream));
+    }
     const dim3 grid((uint32_t)((n + 255) / 256));
     if (c->params.wgsl_compat)
         hipLaunchKernelGGL(k_aabb_pairs<true>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_mn, d_mx, n_prims, d_out);
     else
         hipLaunchKernelGGL(k_aabb_pairs<false>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_mn, d_mx, n_prims, d_out);
     RT_HIP(c, hipGetLastError());
-    RT_HIP(c, hipMemcpyAsync(out_t, d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (!dev) {
+        RT_HIP(c, hipMemcpyAsync(out_t, d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return RT_OK;
 }
 
@@ -789,22 +799,30 @@ extern "C" int rt_intersect_tri_pairs(rt_ctx* c, const float* origins, const flo
     if (n == 0) return RT_OK;
     if (!origins || !dirs || !v012 || !out_t) return fail(c, RT_ERR_INVALID, "rt_intersect_tri_pairs: NULL argument");
     if (n > 0x7FFFFFFFull * 256) return fail(c, RT_ERR_LIMIT, "rt_intersect_tri_pairs: too many pairs");
+    const bool dev = is_device_ptr(out_t);
+    if (dev != is_device_ptr(origins) || dev != is_device_ptr(dirs) || dev != is_device_ptr(v012))
+        return fail(c, RT_ERR_INVALID, "rt_intersect_tri_pairs: arguments must be all host or all device memory");
     const size_t rb = (size_t)n_rays * 12, pb = (size_t)n_prims * 36;
-    RT_HIP(c, c->misc.reserve(2 * rb + pb + n * sizeof(float) + 64));
-    char* base = c->misc.as<char>();
-    float *d_o = (float*)base, *d_d = (float*)(base + rb), *d_v = (float*)(base + 2 * rb),
-          *d_out = (float*)(base + 2 * rb + pb);
-    RT_HIP(c, hipMemcpyAsync(d_o, origins, rb, hipMemcpyHostToDevice, c->stream));
-    RT_HIP(c, hipMemcpyAsync(d_d, dirs, rb, hipMemcpyHostToDevice, c->stream));
-    RT_HIP(c, hipMemcpyAsync(d_v, v012, pb, hipMemcpyHostToDevice, c->stream));
+    const float *d_o = origins, *d_d = dirs, *d_v = v012;
+    float* d_out = out_t;
+    if (!dev) {
+        RT_HIP(c, c->misc.reserve(2 * rb + pb + n * sizeof(float) + 64));
+        char* base = c->misc.as<char>();
+        d_o = (float*)base, d_d = (float*)(base + rb), d_v = (float*)(base + 2 * rb), d_out = (float*)(base + 2 * rb + pb);
+        RT_HIP(c, hipMemcpyAsync((void*)d_o, origins, rb, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync((void*)d_d, dirs, rb, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync((void*)d_v, v012, pb, hipMemcpyHostToDevice, c->stream));
+    }
     const dim3 grid((uint32_t)((n + 255) / 256));
     if (c->params.wgsl_compat)
         hipLaunchKernelGGL(k_tri_pairs<true>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_v, n_prims, d_out);
     else
         hipLaunchKernelGGL(k_tri_pairs<false>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_v, n_prims, d_out);
     RT_HIP(c, hipGetLastError());
-    RT_HIP(c, hipMemcpyAsync(out_t, d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (!dev) {
+        RT_HIP(c, hipMemcpyAsync(out_t, d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return RT_OK;
 }
 

@@ -5,8 +5,9 @@
 // reference are not produced: its shader never reads them (raytracer_unified.wgsl:134 is the
 // only mention).
 //
-// Passes: bounds reduction -> per-cell counts (atomics) -> exclusive scan -> fill (atomics,
-// arbitrary order) -> per-cell sort by id -> cap + compaction -> 48-byte reference records.
+// Passes: bounds reduction -> (object, cell) pairs per object + scan -> per-cell counts (one lane per pair,
+// atomics) -> exclusive scan -> fill (one lane per pair, atomics, arbitrary order) -> per-cell sort by id ->
+// cap + compaction -> 48-byte reference records -> re-test masks.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -108,26 +109,56 @@ __device__ inline Range3 cell_range(const BinGrid& g, V3 omin, V3 omax) {
     return r;
 }
 
+// Number of (object, cell) pairs each object contributes = volume of its cell range.
+__global__ __launch_bounds__(256) void k_obj_pairs(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                                                   uint32_t* __restrict__ obj_n) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = g.nb + g.nt;
+    if (id > total) return;
+    uint32_t n = 0;
+    if (id < total) {
+        V3 mn, mx;
+        object_bounds(boxes, tri_v, g.nb, id, mn, mx);
+        const Range3 r = cell_range(g, mn, mx);
+        // saturate: the host rejects totals beyond its limit, a wrapped product would slip through
+        const unsigned long long v = (unsigned long long)(r.hi[0] - r.lo[0] + 1) * (unsigned long long)(r.hi[1] - r.lo[1] + 1) *
+                                     (unsigned long long)(r.hi[2] - r.lo[2] + 1);
+        n = r.lo[0] > r.hi[0] ? 0u : (v > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)v);
+    }
+    obj_n[id] = n;  // entry `total` is the scan's closing element
+}
+
+// One lane per (object, cell) pair, so an object that spans thousands of cells (a ground plane) is spread over
+// thousands of lanes instead of one lane's loop. obj_off = exclusive scan of the per-object pair counts.
+// COUNT pass: counts[cell]++.  FILL pass: append the id to the cell's segment (order inside a cell is arbitrary
+// here, the per-cell sort that follows makes it ascending).
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                                             const uint32_t* __restrict__ obj_off, uint32_t n_pairs,
                                              uint32_t* __restrict__ counts, const uint32_t* __restrict__ tmp_start,
                                              uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_cell) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= g.nb + g.nt) return;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    // object of this pair: last id with obj_off[id] <= p (objects without cells share their successor's offset)
+    uint32_t lo = 0, hi = g.nb + g.nt;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (obj_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    const uint32_t id = lo;
     V3 mn, mx;
     object_bounds(boxes, tri_v, g.nb, id, mn, mx);
     const Range3 r = cell_range(g, mn, mx);
-    for (int z = r.lo[2]; z <= r.hi[2]; ++z)
-        for (int y = r.lo[1]; y <= r.hi[1]; ++y)
-            for (int x = r.lo[0]; x <= r.hi[0]; ++x) {
-                const uint32_t c = (uint32_t)x + (uint32_t)y * g.gx + (uint32_t)z * g.gx * g.gy;
-                const uint32_t slot = atomicAdd(&counts[c], 1u);
-                if (FILL) {
-                    const uint32_t dst = tmp_start[c] + slot;
-                    tmp_ids[dst] = id;
-                    tmp_cell[dst] = c;
-                }
-            }
+    const uint32_t nx = (uint32_t)(r.hi[0] - r.lo[0] + 1), ny = (uint32_t)(r.hi[1] - r.lo[1] + 1);
+    const uint32_t j = p - obj_off[id];
+    const uint32_t x = (uint32_t)r.lo[0] + j % nx, y = (uint32_t)r.lo[1] + (j / nx) % ny, z = (uint32_t)r.lo[2] + j / (nx * ny);
+    const uint32_t c = x + y * g.gx + z * g.gx * g.gy;
+    const uint32_t slot = atomicAdd(&counts[c], 1u);
+    if (FILL) {
+        const uint32_t dst = tmp_start[c] + slot;
+        tmp_ids[dst] = id;
+        tmp_cell[dst] = c;
+    }
 }
 
 // Re-test masks. A reference (cell C, object T) gets bit 2a (2a+1) set when the cell one step back along axis a
@@ -269,35 +300,59 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
     g.nb = nb, g.nt = nt;
     g.tri_mode = tri_mode ? 1 : 0;
 
-    // ---- count
+    // ---- pairs per object, their scan, per-cell counts
     const size_t cell_bytes = ((size_t)n_cells + 1) * sizeof(uint32_t);
     RT_HIP(c, c->b_counts.reserve(cell_bytes));
     RT_HIP(c, c->b_tmp_start.reserve(cell_bytes));
     RT_HIP(c, c->b_cursor.reserve(cell_bytes));
     RT_HIP(c, c->cell_start.reserve(cell_bytes));
+    RT_HIP(c, c->b_obj_n.reserve(((size_t)total + 1) * sizeof(uint32_t)));
+    RT_HIP(c, c->b_obj_off.reserve(((size_t)total + 1) * sizeof(uint32_t)));
     uint32_t* counts = c->b_counts.as<uint32_t>();
     uint32_t* tmp_start = c->b_tmp_start.as<uint32_t>();
     uint32_t* cursor = c->b_cursor.as<uint32_t>();
     uint32_t* final_start = c->cell_start.as<uint32_t>();
+    uint32_t* obj_n = c->b_obj_n.as<uint32_t>();
+    uint32_t* obj_off = c->b_obj_off.as<uint32_t>();
     RT_HIP(c, hipMemsetAsync(counts, 0, cell_bytes, st));
     RT_HIP(c, hipMemsetAsync(cursor, 0, cell_bytes, st));
-    const dim3 obj_grid((total + 255) / 256);
+    size_t scan_bytes = 0;
+    unsigned long long n_pairs64 = 0;
     if (total) {
-        hipLaunchKernelGGL(k_bin<false>, obj_grid, dim3(256), 0, st, g, c->boxes.as<BoxData>(), c->tri_v.as<float>(), counts,
-                           (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_obj_pairs, dim3((total + 1 + 255) / 256), dim3(256), 0, st, g, c->boxes.as<BoxData>(),
+                           c->tri_v.as<float>(), obj_n);
+        RT_HIP(c, hipGetLastError());
+        // 64-bit sums: the total is checked against the limit below before anything is sized by it
+        RT_HIP(c, c->b_obj_sum.reserve(sizeof(unsigned long long)));
+        size_t red_bytes = 0;
+        RT_HIP(c, rocprim::reduce(nullptr, red_bytes, obj_n, c->b_obj_sum.as<unsigned long long>(), 0ull, (size_t)total,
+                                  rocprim::plus<unsigned long long>(), st));
+        RT_HIP(c, c->b_scan_tmp.reserve(red_bytes + 256));
+        RT_HIP(c, rocprim::reduce(c->b_scan_tmp.p, red_bytes, obj_n, c->b_obj_sum.as<unsigned long long>(), 0ull, (size_t)total,
+                                  rocprim::plus<unsigned long long>(), st));
+        RT_HIP(c, rocprim::exclusive_scan(nullptr, scan_bytes, obj_n, obj_off, 0u, (size_t)total + 1, rocprim::plus<uint32_t>(), st));
+        RT_HIP(c, c->b_scan_tmp.reserve(scan_bytes + 256));
+        RT_HIP(c, rocprim::exclusive_scan(c->b_scan_tmp.p, scan_bytes, obj_n, obj_off, 0u, (size_t)total + 1,
+                                          rocprim::plus<uint32_t>(), st));
+        RT_HIP(c, hipMemcpyAsync(&n_pairs64, c->b_obj_sum.p, sizeof(n_pairs64), hipMemcpyDeviceToHost, st));
+        RT_HIP(c, hipStreamSynchronize(st));
+    }
+    if (n_pairs64 > 0xFFFFFFF0ull / 2)
+        return fail(c, RT_ERR_LIMIT, "rt_build_grid: %llu cell references (max %u)", n_pairs64, 0xFFFFFFF0u / 2);
+    const uint32_t n_tmp = (uint32_t)n_pairs64;
+    const dim3 pair_grid((n_tmp + 255) / 256);
+    if (n_tmp) {
+        hipLaunchKernelGGL(k_bin<false>, pair_grid, dim3(256), 0, st, g, c->boxes.as<BoxData>(), c->tri_v.as<float>(),
+                           (const uint32_t*)obj_off, n_tmp, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr);
         RT_HIP(c, hipGetLastError());
     }
 
     // ---- scan of the uncapped counts: where each cell's unsorted ids go
-    size_t scan_bytes = 0;
     RT_HIP(c, rocprim::exclusive_scan(nullptr, scan_bytes, counts, tmp_start, 0u, (size_t)n_cells + 1, rocprim::plus<uint32_t>(), st));
     RT_HIP(c, c->b_scan_tmp.reserve(scan_bytes + 256));
     RT_HIP(c, rocprim::exclusive_scan(c->b_scan_tmp.p, scan_bytes, counts, tmp_start, 0u, (size_t)n_cells + 1,
                                       rocprim::plus<uint32_t>(), st));
-    uint32_t n_tmp = 0;
-    RT_HIP(c, hipMemcpyAsync(&n_tmp, tmp_start + n_cells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    RT_HIP(c, hipStreamSynchronize(st));
-    if (n_tmp > 0xFFFFFFF0u / 2) return fail(c, RT_ERR_LIMIT, "rt_build_grid: %u cell references", n_tmp);
 
     uint32_t n_refs = 0;
     if (n_tmp) {
@@ -309,8 +364,8 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
         uint32_t* tmp_ids = c->b_tmp_ids.as<uint32_t>();
         uint32_t* tmp_sorted = c->b_tmp_sorted.as<uint32_t>();
         uint32_t* tmp_cell = c->b_tmp_cell.as<uint32_t>();
-        hipLaunchKernelGGL(k_bin<true>, obj_grid, dim3(256), 0, st, g, c->boxes.as<BoxData>(), c->tri_v.as<float>(), cursor,
-                           (const uint32_t*)tmp_start, tmp_ids, tmp_cell);
+        hipLaunchKernelGGL(k_bin<true>, pair_grid, dim3(256), 0, st, g, c->boxes.as<BoxData>(), c->tri_v.as<float>(),
+                           (const uint32_t*)obj_off, n_tmp, cursor, (const uint32_t*)tmp_start, tmp_ids, tmp_cell);
         RT_HIP(c, hipGetLastError());
         size_t sort_bytes = 0;
         RT_HIP(c, rocprim::segmented_radix_sort_keys(nullptr, sort_bytes, tmp_ids, tmp_sorted, n_tmp, n_cells, tmp_start,

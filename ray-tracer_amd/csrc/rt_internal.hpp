@@ -72,7 +72,8 @@ struct rt_ctx {
     rt::DevBuf box_frame;   // float4[4*nb]
 
     // binning scratch
-    rt::DevBuf b_partial, b_counts, b_tmp_start, b_cursor, b_tmp_ids, b_tmp_sorted, b_tmp_cell, b_scan_tmp, b_flags;
+    rt::DevBuf b_partial, b_counts, b_tmp_start, b_cursor, b_tmp_ids, b_tmp_sorted, b_tmp_cell, b_scan_tmp, b_flags,
+        b_obj_n, b_obj_off, b_obj_sum;
 
     // per-call scratch
     rt::DevBuf out_p, out_s, in_o, in_d, stats, misc;

@@ -243,7 +243,12 @@ class TraceCore:
         return s.as_dict()
 
     # ---- primitive routines
-    def intersect_aabb_pairs(self, origins, dirs, box_min, box_max):
+    def intersect_aabb_pairs(self, origins, dirs, box_min, box_max, out=None):
+        """numpy in -> numpy out; with `out` a device tensor, all arguments are float32 device tensors (n,3)."""
+        if out is not None:
+            self._ck(self._L.rt_intersect_aabb_pairs(self._h, _ptr(origins), _ptr(dirs), origins.shape[0], _ptr(box_min),
+                                                     _ptr(box_max), box_min.shape[0], _ptr(out)))
+            return out
         origins, dirs, box_min, box_max = (np.ascontiguousarray(a, np.float32).reshape(-1, 3)
                                            for a in (origins, dirs, box_min, box_max))
         out = np.empty((len(origins), len(box_min)), np.float32)
@@ -251,7 +256,11 @@ class TraceCore:
                                                  _ptr(box_max), len(box_min), _ptr(out)))
         return out
 
-    def intersect_tri_pairs(self, origins, dirs, v012):
+    def intersect_tri_pairs(self, origins, dirs, v012, out=None):
+        if out is not None:  # device tensors throughout
+            self._ck(self._L.rt_intersect_tri_pairs(self._h, _ptr(origins), _ptr(dirs), origins.shape[0], _ptr(v012),
+                                                    v012.shape[0], _ptr(out)))
+            return out
         origins, dirs = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (origins, dirs))
         v012 = np.ascontiguousarray(v012, np.float32).reshape(-1, 9)
         out = np.empty((len(origins), len(v012)), np.float32)

@@ -107,7 +107,11 @@ const char* rt_last_error(const rt_ctx* ctx);
 const char* rt_create_error(void);
 
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the
- * context's own; NULL restores the context's stream. */
+ * context's own; NULL restores the context's stream. Does not block the host: alternating
+ * between streams keeps several frames in flight (each with its own output buffers), which
+ * hides the long tail of a frame behind the next one. The context orders its own per-frame
+ * scratch across the switch on the GPU, and rt_set_scene / rt_set_grid_* / rt_build_grid /
+ * rt_update_vertices wait for every stream used before; rt_sync waits for all of them. */
 int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 /* Blocks until everything queued by this context has finished. */
 int rt_sync(rt_ctx* ctx);

@@ -157,6 +157,16 @@ int use(rt_ctx* c) {
     return RT_OK;
 }
 
+// Before the scene or the grid is replaced: nothing queued on any stream may still read the old one.
+int scene_barrier(rt_ctx* c) {
+    if (c->other_streams_busy) {
+        RT_HIP(c, hipDeviceSynchronize());
+        c->other_streams_busy = false;
+        c->scratch_busy = false;
+    }
+    return RT_OK;
+}
+
 DevScene make_scene(const rt_ctx* c) {
     DevScene s;
     memset(&s, 0, sizeof(s));
@@ -214,6 +224,7 @@ int update_box_frame(rt_ctx* c, const CameraUniform* cam) {
     if (c->grid_nb == 0) return RT_OK;
     if (!cam) return fail(c, RT_ERR_INVALID, "camera is required when the scene has boxes (LOD cull, box motion)");
     RT_HIP(c, c->box_frame.reserve((size_t)c->nb * 4 * sizeof(float4)));
+    c->scratch_busy = true;
     float t_lerp = (sinf(cam->time * 2.0f) + 1.0f) * 0.5f;  // raytracer_unified.wgsl:201,449
     hipLaunchKernelGGL(k_box_frame, dim3((c->nb + 255) / 256), dim3(256), 0, c->stream, c->boxes.as<BoxData>(), c->nb,
                        t_lerp, ld3(cam->position), cam->lod_factor, cam->min_pixel_size, c->params.lod_cull,
@@ -392,7 +403,8 @@ extern "C" int rt_create(rt_ctx** out, int device_id, const rt_params* params) {
     memset(&c->meta, 0, sizeof(c->meta));
     memset(&c->last_stats, 0, sizeof(c->last_stats));
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming)) != hipSuccess) {
         g_create_error = std::string("rt_create: stream/event creation: ") + hipGetErrorString(e);
         delete c;
         return RT_ERR_NO_DEVICE;
@@ -413,22 +425,43 @@ extern "C" void rt_destroy(rt_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
 extern "C" const char* rt_last_error(const rt_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
+// Switching streams does not block the host, so a caller can keep several frames in flight by alternating
+// streams (the last waves of a frame - a few pixel blocks over the densest cells - then overlap the next frame's
+// bulk). Ordering rules the context keeps by itself:
+//   - work that uses the context's per-frame scratch (box records of scenes with boxes) is ordered across the
+//     switch on the GPU: the new stream waits for it,
+//   - calls that replace the scene or the grid first wait for every stream used before (scene_barrier).
+// Output buffers are the caller's: a frame in flight must not share them with another.
 extern "C" int rt_set_stream(rt_ctx* c, void* hip_stream) {
     if (int r = use(c)) return r;
-    RT_HIP(c, hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    hipStream_t next = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    if (next == c->stream) return RT_OK;
+    if (c->scratch_busy) {
+        RT_HIP(c, hipEventRecord(c->ev_order, c->stream));
+        RT_HIP(c, hipStreamWaitEvent(next, c->ev_order, 0));
+        c->scratch_busy = false;
+    }
+    c->other_streams_busy = true;
+    c->stream = next;
     return RT_OK;
 }
 
 extern "C" int rt_sync(rt_ctx* c) {
     if (int r = use(c)) return r;
-    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->other_streams_busy) {  // frames may be in flight on streams used before the current one
+        RT_HIP(c, hipDeviceSynchronize());
+        c->other_streams_busy = false;
+    } else {
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->scratch_busy = false;
     return RT_OK;
 }
 
@@ -468,6 +501,7 @@ extern "C" int rt_set_scene(rt_ctx* c, const BoxData* boxes, uint32_t nb, const 
     if (int r = use(c)) return r;
     if ((nb && !boxes) || (nt && !tris)) return fail(c, RT_ERR_INVALID, "rt_set_scene: NULL array with non-zero count");
     if ((uint64_t)nb + nt >= 0xFFFFFFF0ull) return fail(c, RT_ERR_LIMIT, "rt_set_scene: more than 2^32-16 objects");
+    if (int r = scene_barrier(c)) return r;
     c->has_grid = false;
     c->nb = nb;
     c->nt = nt;
@@ -506,6 +540,7 @@ static int install_csr(rt_ctx* c, const GridMetadata* meta, const uint32_t* cell
     uint32_t n_refs = cell_start[n_cells];
     for (size_t k = 0; k < n_cells; ++k)
         if (cell_start[k + 1] < cell_start[k]) return fail(c, RT_ERR_INVALID, "cell_start is not non-decreasing at %zu", k);
+    if (int r = scene_barrier(c)) return r;
     c->meta = *meta;
     c->grid_nb = c->nb;
     c->n_cells = (uint32_t)n_cells;
@@ -567,6 +602,7 @@ extern "C" int rt_build_grid(rt_ctx* c, float cell_size, uint32_t max_per_cell, 
     if (!(cell_size > 0.0f)) cell_size = c->params.finest_cell_size;
     if (max_per_cell == 0)
         max_per_cell = mode == RT_GRID_TRIANGLES ? RT_TRI_MAX_TRIANGLES_PER_CELL : c->params.max_objects_per_cell;
+    if (int r = scene_barrier(c)) return r;
     c->has_grid = false;
     if (int r = build_grid_device(c, cell_size, max_per_cell, mode)) return r;
     c->has_grid = true;
@@ -600,6 +636,7 @@ extern "C" int rt_update_vertices(rt_ctx* c, const float* xyz9, uint32_t first, 
     if (!xyz9 && count) return fail(c, RT_ERR_INVALID, "rt_update_vertices: xyz9 is NULL");
     if ((uint64_t)first + count > c->nt) return fail(c, RT_ERR_INVALID, "rt_update_vertices: range beyond %u triangles", c->nt);
     if (!count) return RT_OK;
+    if (int r = scene_barrier(c)) return r;
     const bool dev = is_device_ptr(xyz9);
     RT_HIP(c, hipMemcpyAsync(c->tri_v.as<float>() + 9 * (size_t)first, xyz9, (size_t)count * 9 * sizeof(float),
                              dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));

@@ -79,6 +79,10 @@ struct rt_ctx {
     rt::DevBuf out_p, out_s, in_o, in_d, stats, misc;
     rt_stats last_stats;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Frames in flight on several streams (rt_set_stream): see the rules at rt_set_stream in rt_api.hip.
+    hipEvent_t ev_order = nullptr;
+    bool scratch_busy = false;        // work using the context's per-frame scratch is queued on the current stream
+    bool other_streams_busy = false;  // a stream used earlier may still hold trace work that reads the scene
 };
 
 namespace rt {

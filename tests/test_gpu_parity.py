@@ -520,6 +520,39 @@ def test_runs_on_torch_stream(core, ob, rt, car_xyz9):
     core.set_stream(None)
 
 
+def test_frames_in_flight_on_two_streams(core, ob, rt):
+    """Consecutive frames on alternating streams, each with its own output buffers, nothing synchronised in
+    between. The scene has moving boxes, whose per-frame records live in scratch memory of the context that all
+    frames share: the context has to order that itself. Then the scene is replaced while frames are in flight."""
+    import torch
+    boxes = random_boxes(ob, 80, 4, extent=50.0, moving_last=3)
+    tris = ob.generate_test_triangles(2000)
+    scene = setup_scene(core, ob, boxes, tris, cell_size=8.0)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    w, h = 192, 108
+    times = [0.0, 0.31, 0.77, 1.9, 2.4, 3.3]
+    cams = [rt.Camera((5, 25, 150), math.pi, -0.15).to_uniform(t, float(h)) for t in times]
+    outs = [(torch.empty((w * h, 2), dtype=torch.int32, device="cuda"), torch.empty((w * h, 2), dtype=torch.int32, device="cuda"))
+            for _ in times]
+    for k, cam in enumerate(cams):
+        core.set_stream(streams[k % 2].cuda_stream)
+        core.trace_primary(cam, w, h, out_primary=outs[k][0], out_shadow=outs[k][1])
+    tris2 = ob.generate_test_triangles(500)
+    core.set_scene(boxes, tris2)  # must wait for every frame above
+    core.build_grid(cell_size=8.0)
+    last = core.trace_primary(cams[0], w, h)
+    core.set_stream(None)
+    core.sync()
+    for k, cam in enumerate(cams):
+        op, os_, _ = ob.trace_primary(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params))
+        assert_hits_equal(outs[k][0].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), op, f"frame {k} primary")
+        assert_hits_equal(outs[k][1].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), os_, f"frame {k} shadow")
+    scene2 = ob.Scene(boxes, tris2, cell_size=8.0)
+    op, os_, _ = ob.trace_primary(scene2, ocam(ob, cams[0]), w, h, params=oparams(ob, core.params))
+    assert_hits_equal(last[0], op, "after scene change")
+    assert_hits_equal(last[1], os_, "after scene change")
+
+
 def test_errors_are_reported(core, rt, ob):
     with pytest.raises(rt.RtError) as e:
         core.trace_primary(rt.Camera.for_scene("gltf").to_uniform(), 8, 8)

@@ -192,6 +192,37 @@ int rt_assemble_tiles(rt_ctx* ctx, const rt_hit* gathered, uint32_t width, uint3
 int rt_debug_pixel(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
                    uint32_t px, uint32_t py, RayDebugInfo* info);
 
+/* ---- shaded picture ------------------------------------------------------------------- */
+
+/* What main() of the shader does around trace_ray, beyond its constants. */
+typedef struct rt_render_opts {
+    uint32_t max_bounces;     /* MAX_BOUNCES (src/raytracer_unified.wgsl:656): 8 */
+    uint32_t shadows;         /* 0 = the shader's lighting. 1 = a shaded point whose shadow ray (as defined at
+                                 rt_trace_primary) is occluded receives no diffuse light - not in the shader */
+    uint32_t debug_enabled;   /* DebugParams (src/types.rs:187-193): highlight of the debug pixel, wgsl:693-716 */
+    uint32_t debug_pixel[2];
+    uint32_t _pad[3];
+} rt_render_opts;
+void rt_default_render_opts(rt_render_opts* o);
+
+/* Replaces the "Materials" storage buffer (src/renderer.rs:147-156): MaterialData records
+ * indexed by TriangleData::material_id. Without it every triangle is the shader's grey
+ * (wgsl:366-370). Textures, normal maps and the alpha modes are not evaluated yet. */
+int rt_set_materials(rt_ctx* ctx, const MaterialData* materials, uint32_t n);
+
+/* Replaces dispatch_workgroups + the Rgba8Unorm output texture (src/renderer.rs:822-868,
+ * src/core/ray_tracing_layer.rs:436-493 which returns these bytes): ray generation, up to
+ * max_bounces trace_ray calls per pixel with mirror reflection, sky, ambient + directional
+ * lighting, grid overlay (camera.show_grid), debug-pixel highlight; out_rgba8 gets 4 bytes per
+ * pixel (r, g, b, 255), row-major, or tile-packed exactly like rt_trace_primary's records
+ * when shard is given. Host or device pointer, as for rt_trace_primary. */
+int rt_render(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height, const rt_shard* shard,
+              const rt_render_opts* opts, uint8_t* out_rgba8);
+
+/* rt_assemble_tiles for rt_render's 4-byte pixels. No reference counterpart. */
+int rt_assemble_tiles_rgba8(rt_ctx* ctx, const uint8_t* gathered, uint32_t width, uint32_t height,
+                            uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, uint8_t* image);
+
 /* Counters of the most recent trace call made with params.collect_stats = 1. */
 int rt_get_stats(rt_ctx* ctx, rt_stats* stats);
 int rt_set_collect_stats(rt_ctx* ctx, int enabled);

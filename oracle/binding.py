@@ -23,6 +23,9 @@ BOX_DTYPE = np.dtype([("min", f32, 3), ("is_moving", f32), ("max", f32, 3), ("_p
                       ("reflectivity", f32), ("center0", f32, 3), ("_pad4", f32), ("center1", f32, 3), ("_pad5", f32),
                       ("half_size", f32, 3), ("_pad6", f32)])
 HIT_DTYPE = np.dtype([("id", u32), ("t", f32)])
+MATERIAL_DTYPE = np.dtype([("base_color", f32, 4), ("emissive", f32, 3), ("texture_index", np.int32), ("metallic", f32),
+                           ("roughness", f32), ("normal_texture_index", np.int32), ("emissive_texture_index", np.int32),
+                           ("alpha_mode", u32), ("alpha_cutoff", f32), ("_pad", f32, 2)])
 assert TRIANGLE_DTYPE.itemsize == 80 and BOX_DTYPE.itemsize == 96 and HIT_DTYPE.itemsize == 8
 MISS = 0xFFFFFFFF
 GRID_HIERARCHICAL, GRID_TRIANGLES = 0, 1
@@ -69,6 +72,11 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [("max_bounces", C.c_uint32), ("shadows", C.c_uint32), ("debug_enabled", C.c_uint32),
+                ("debug_pixel", C.c_uint32 * 2), ("_pad", C.c_uint32 * 3)]
 
 
 class RayDebugInfo(C.Structure):
@@ -147,6 +155,10 @@ def lib():
         L.orc_trace_primary.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32,
                                         C.c_uint32, C.POINTER(Shard), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(Stats), C.c_int]
+        L.orc_render.restype = None
+        L.orc_render.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32, C.c_uint32,
+                                 C.POINTER(Shard), C.c_void_p, C.c_uint32, C.POINTER(RenderOpts), C.c_void_p,
+                                 C.POINTER(Stats), C.c_int]
         L.orc_primary_rays.restype = None
         L.orc_primary_rays.argtypes = [C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32, C.c_uint32,
                                        C.c_void_p, C.c_void_p]
@@ -416,6 +428,25 @@ def trace_primary(scene, cam, width, height, params=None, shard=None, shadow=Tru
     if want_shadow_rays:
         return prim, shad, st.as_dict(), so, sd
     return prim, shad, st.as_dict()
+
+
+def render(scene, cam, width, height, params=None, shard=None, materials=None, max_bounces=8, shadows=False,
+           debug_pixel=None, n_threads=None):
+    """Returns ((n_pixels, 4) uint8 RGBA, stats dict)."""
+    params = params or Params.default()
+    n_threads = n_threads or os.cpu_count() or 1
+    n = shard_pixels(width, height, shard)
+    out = np.empty((n, 4), np.uint8)
+    mats = _c(materials if materials is not None else np.zeros(0, MATERIAL_DTYPE), MATERIAL_DTYPE)
+    o = RenderOpts()
+    o.max_bounces, o.shadows = max_bounces, 1 if shadows else 0
+    if debug_pixel is not None:
+        o.debug_enabled, o.debug_pixel[0], o.debug_pixel[1] = 1, debug_pixel[0], debug_pixel[1]
+    st = Stats()
+    lib().orc_render(C.byref(scene._s), C.byref(params), C.byref(cam), width, height,
+                     C.byref(shard) if shard is not None else None, _ptr(mats), len(mats), C.byref(o), _ptr(out),
+                     C.byref(st), n_threads)
+    return out, st.as_dict()
 
 
 def primary_rays(cam, width, height, params=None):

@@ -836,6 +836,124 @@ extern "C" void orc_trace_primary(const orc_scene* s, const rt_params* p, const 
     }
 }
 
+// ---- shaded picture: raytracer_unified.wgsl:590-621 (sky, lighting), :655-720 (bounce loop, debug pixel,
+// texture store), :230-233 (box colour), :280-303,345-370 (untextured material). Textures, normal maps and the
+// alpha modes are not restated (the GPU path does not evaluate them either).
+namespace {
+
+inline uint32_t unorm8(float c) {
+    float x = fminf(fmaxf(c, 0.0f), 1.0f);
+    return (uint32_t)rintf(x * 255.0f);  // round to nearest even
+}
+
+// :419-428 (WGSL % on f32 = truncated remainder)
+inline bool near_grid_boundary(const orc_scene& s, V3 pos, float threshold) {
+    V3 rel = pos - ld(s.meta.bounds_min);
+    float cs = s.meta.finest_cell_size;
+    V3 local = v3(fmodf(rel.x, cs) / cs, fmodf(rel.y, cs) / cs, fmodf(rel.z, cs) / cs);
+    float dx = fminf(local.x, 1.0f - local.x), dy = fminf(local.y, 1.0f - local.y), dz = fminf(local.z, 1.0f - local.z);
+    return dx < threshold || dy < threshold || dz < threshold;
+}
+
+}  // namespace
+
+extern "C" void orc_render(const orc_scene* s, const rt_params* p, const CameraUniform* cam, uint32_t width, uint32_t height,
+                           const rt_shard* shard, const MaterialData* mats, uint32_t n_mats, const rt_render_opts* opts,
+                           uint8_t* out_rgba8, rt_stats* stats, int n_threads) {
+    const ShardMap m = shard_map(width, height, shard);
+    const FrameConsts fc = frame_consts(*p, cam);
+    const uint64_t per_tile = (uint64_t)m.tile_w * m.tile_h;
+    const uint64_t rows = (uint64_t)m.n_local * m.tile_h;
+    rt_render_opts o;
+    memset(&o, 0, sizeof(o));
+    o.max_bounces = 8;
+    if (opts) o = *opts;
+    std::vector<rt_stats> part((size_t)std::max(1, n_threads));
+    for (auto& q : part) memset(&q, 0, sizeof(q));
+    uint32_t* out = reinterpret_cast<uint32_t*>(out_rgba8);
+    parallel_for(rows, n_threads, [&](uint64_t lo, uint64_t hi, int k) {
+        rt_stats& st_ = part[(size_t)k];
+        for (uint64_t r = lo; r < hi; ++r) {
+            uint32_t lt = (uint32_t)(r / m.tile_h), ly = (uint32_t)(r % m.tile_h);
+            uint32_t tile = m.first + lt * m.stride;
+            uint32_t ty = tile / m.tiles_x, tx = tile % m.tiles_x;
+            uint32_t py = ty * m.tile_h + ly;
+            for (uint32_t lx = 0; lx < m.tile_w; ++lx) {
+                uint32_t px = tx * m.tile_w + lx;
+                uint64_t oi = (uint64_t)lt * per_tile + (uint64_t)ly * m.tile_w + lx;
+                uint32_t rgba = 0;
+                if (px < width && py < height) {
+                    V3 ro = ld(cam->position);
+                    V3 rd = primary_dir(*cam, fc, px, py, width, height);
+                    V3 acc = v3(0, 0, 0);
+                    float mult = 1.0f;
+                    Counters c;
+                    for (uint32_t bounce = 0; bounce < o.max_bounces; ++bounce) {
+                        Hit h = trace_ray(*s, *p, *cam, fc, ro, rd, false, c);
+                        st_.rays++;
+                        if (!h.hit) {
+                            float t = (rd.y + 1.0f) * 0.5f;
+                            acc = acc + mix(v3(0.3f, 0.5f, 0.7f), v3(0.5f, 0.7f, 1.0f), t) * mult;
+                            break;
+                        }
+                        if (bounce == 0) st_.primary_hits++;
+                        V3 color = v3(0.7f, 0.7f, 0.7f), emissive = v3(0, 0, 0);
+                        float refl = 0.0f;
+                        if (h.id < s->nb) {
+                            color = ld(s->boxes[h.id].color);
+                            refl = s->boxes[h.id].reflectivity;
+                        } else {
+                            uint32_t mat = f2u_sat(s->tris[h.id - s->nb].material_id);
+                            if (mat < n_mats) {
+                                color = v3(mats[mat].base_color[0], mats[mat].base_color[1], mats[mat].base_color[2]);
+                                emissive = ld(mats[mat].emissive);
+                                refl = mats[mat].metallic;
+                            }
+                        }
+                        float diffuse = fmaxf(dot(h.n, fc.shadow_dir), 0.0f);
+                        if (o.shadows) {
+                            V3 nf = h.n;
+                            if (dot(nf, rd) > 0.0f) nf = neg(nf);
+                            Hit oh = trace_ray(*s, *p, *cam, fc, h.pos + nf * p->shadow_offset, fc.shadow_dir, true, c);
+                            st_.rays++;
+                            st_.shadow_rays++;
+                            if (oh.hit) {
+                                st_.shadow_hits++;
+                                diffuse = 0.0f;
+                            }
+                        }
+                        V3 lit = color * (0.3f + diffuse * 0.7f) + emissive;
+                        if (cam->show_grid > 0.5f && near_grid_boundary(*s, h.pos, 0.02f)) lit = mix(lit, v3(0, 1, 0), 0.6f);
+                        acc = acc + (lit * (1.0f - refl)) * mult;
+                        if (refl < 0.01f) break;
+                        mult *= refl;
+                        rd = rd - h.n * (2.0f * dot(h.n, rd));
+                        ro = h.pos + h.n * 0.001f;
+                    }
+                    if (o.debug_enabled) {
+                        int dx = (int)px - (int)o.debug_pixel[0], dy = (int)py - (int)o.debug_pixel[1];
+                        if (dx == 0 && dy == 0)
+                            acc = v3(1, 1, 0);
+                        else if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1)
+                            acc = mix(acc, v3(1, 1, 0), 0.5f);
+                    }
+                    rgba = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xFF000000u;
+                }
+                out[oi] = rgba;
+            }
+        }
+    });
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        for (auto& q : part) {
+            stats->rays += q.rays;
+            stats->primary_hits += q.primary_hits;
+            stats->shadow_rays += q.shadow_rays;
+            stats->shadow_hits += q.shadow_hits;
+        }
+    }
+}
+
 extern "C" void orc_primary_rays(const rt_params* p, const CameraUniform* cam, uint32_t width, uint32_t height,
                                  float* origins, float* dirs) {
     const FrameConsts fc = frame_consts(*p, cam);

@@ -96,6 +96,12 @@ typedef struct orc_scene {
 void orc_trace_primary(const orc_scene* s, const rt_params* p, const CameraUniform* cam, uint32_t width,
                        uint32_t height, const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow,
                        float* shadow_o, float* shadow_d, rt_stats* stats, int n_threads);
+/* The shaded picture of the shader's main() (raytracer_unified.wgsl:590-621, 655-720) with untextured materials;
+ * 4 bytes per pixel, packed like orc_trace_primary's records. Parity unpinned by the reference (it has no image
+ * fixture); pinned against itself by tests/test_oracle_golden.py. */
+void orc_render(const orc_scene* s, const rt_params* p, const CameraUniform* cam, uint32_t width, uint32_t height,
+                const rt_shard* shard, const MaterialData* mats, uint32_t n_mats, const rt_render_opts* opts,
+                uint8_t* out_rgba8, rt_stats* stats, int n_threads);
 void orc_primary_rays(const rt_params* p, const CameraUniform* cam, uint32_t width, uint32_t height,
                       float* origins, float* dirs);
 void orc_trace_rays(const orc_scene* s, const rt_params* p, const CameraUniform* cam, const float* origins,

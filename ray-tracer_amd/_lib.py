@@ -22,7 +22,11 @@ BOX_DTYPE = np.dtype([("min", f32, 3), ("is_moving", f32), ("max", f32, 3), ("_p
                       ("reflectivity", f32), ("center0", f32, 3), ("_pad4", f32), ("center1", f32, 3), ("_pad5", f32),
                       ("half_size", f32, 3), ("_pad6", f32)])
 HIT_DTYPE = np.dtype([("id", u32), ("t", f32)])
+MATERIAL_DTYPE = np.dtype([("base_color", f32, 4), ("emissive", f32, 3), ("texture_index", np.int32), ("metallic", f32),
+                           ("roughness", f32), ("normal_texture_index", np.int32), ("emissive_texture_index", np.int32),
+                           ("alpha_mode", u32), ("alpha_cutoff", f32), ("_pad", f32, 2)])
 assert TRIANGLE_DTYPE.itemsize == 80 and BOX_DTYPE.itemsize == 96 and HIT_DTYPE.itemsize == 8
+assert MATERIAL_DTYPE.itemsize == 64
 
 RT_MISS = 0xFFFFFFFF
 RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_STATE, RT_ERR_LIMIT = 0, -1, -2, -3, -4, -5
@@ -65,6 +69,11 @@ class RtStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class RtRenderOpts(C.Structure):
+    _fields_ = [("max_bounces", C.c_uint32), ("shadows", C.c_uint32), ("debug_enabled", C.c_uint32),
+                ("debug_pixel", C.c_uint32 * 2), ("_pad", C.c_uint32 * 3)]
+
+
 class RayDebugInfo(C.Structure):
     _fields_ = [("ray_origin", C.c_float * 3), ("hit", C.c_float), ("ray_direction", C.c_float * 3),
                 ("distance", C.c_float), ("hit_position", C.c_float * 3), ("object_id", C.c_float),
@@ -95,6 +104,10 @@ PROTOTYPES = {
     "rt_trace_primary": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), _VP, _VP]),
     "rt_trace_rays": (_I, [_VP, C.POINTER(CameraUniform), _VP, _VP, _U32, _VP, _I]),
     "rt_assemble_tiles": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
+    "rt_assemble_tiles_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
+    "rt_default_render_opts": (None, [C.POINTER(RtRenderOpts)]),
+    "rt_set_materials": (_I, [_VP, _VP, _U32]),
+    "rt_render": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), C.POINTER(RtRenderOpts), _VP]),
     "rt_debug_pixel": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, _U32, _U32, C.POINTER(RayDebugInfo)]),
     "rt_get_stats": (_I, [_VP, C.POINTER(RtStats)]),
     "rt_set_collect_stats": (_I, [_VP, _I]),

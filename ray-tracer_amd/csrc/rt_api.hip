@@ -11,6 +11,7 @@
 
 #include "rt_trace_variants.hpp"
 #endif
+#include "rt_render.hpp"
 
 using namespace rt;
 
@@ -101,10 +102,12 @@ __global__ void k_tri_normals(const float* __restrict__ tri_v, uint32_t first, u
     out[first + i] = make_float4(n.x, n.y, n.z, 0.f);
 }
 
-__global__ void k_tri_unpack(const TriangleData* __restrict__ tris, uint32_t nt, float* __restrict__ tri_v) {
+__global__ void k_tri_unpack(const TriangleData* __restrict__ tris, uint32_t nt, float* __restrict__ tri_v,
+                             uint32_t* __restrict__ tri_mat) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nt) return;
     const TriangleData t = tris[i];
+    tri_mat[i] = f2u_sat(t.material_id);  // u32(tri.material_id), raytracer_unified.wgsl:280
     float* o = tri_v + 9 * (size_t)i;
     o[0] = t.v0[0], o[1] = t.v0[1], o[2] = t.v0[2];
     o[3] = t.v1[0], o[4] = t.v1[1], o[5] = t.v1[2];
@@ -137,9 +140,10 @@ __global__ void k_tri_pairs(const float* __restrict__ o, const float* __restrict
                                       make_float4(e1.x, e1.y, e1.z, 0.f), make_float4(e2.x, e2.y, e2.z, 0.f));
 }
 
-__global__ void k_assemble(const uint2* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+template <class PIXEL>
+__global__ void k_assemble(const PIXEL* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w,
                            uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks, size_t per_rank,
-                           uint2* __restrict__ image) {
+                           PIXEL* __restrict__ image) {
     uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= width || y >= height) return;
     uint32_t tile = (y / tile_h) * tiles_x + (x / tile_w);
@@ -418,7 +422,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->tri_n,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
+    DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->tri_n,     &c->tri_mat,   &c->materials,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
                       &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->b_obj_n, &c->b_obj_off, &c->b_obj_sum, &c->out_p,     &c->out_s,
                       &c->in_o,      &c->in_d,      &c->stats,      &c->misc};
@@ -512,8 +516,9 @@ extern "C" int rt_set_scene(rt_ctx* c, const BoxData* boxes, uint32_t nb, const 
         // 80-byte records in, 36-byte vertex records kept: the rest (uv, material) is not geometry
         RT_HIP(c, c->misc.reserve((size_t)nt * sizeof(TriangleData)));
         RT_HIP(c, hipMemcpyAsync(c->misc.p, tris, (size_t)nt * sizeof(TriangleData), hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, c->tri_mat.reserve((size_t)nt * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_tri_unpack, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->misc.as<TriangleData>(), nt,
-                           c->tri_v.as<float>());
+                           c->tri_v.as<float>(), c->tri_mat.as<uint32_t>());
         RT_HIP(c, hipGetLastError());
         RT_HIP(c, c->tri_n.reserve((size_t)nt * sizeof(float4)));
         hipLaunchKernelGGL(k_tri_normals, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->tri_v.as<float>(), 0u, nt,
@@ -753,21 +758,109 @@ extern "C" int rt_trace_rays(rt_ctx* c, const CameraUniform* cam, const float* o
     return RT_OK;
 }
 
-extern "C" int rt_assemble_tiles(rt_ctx* c, const rt_hit* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
-                                 uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, rt_hit* image) {
+template <class PIXEL>
+static int assemble_tiles(rt_ctx* c, const void* gathered, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
+                          uint32_t n_ranks, size_t rank_stride, void* image, const char* who) {
     if (int r = use(c)) return r;
     if (!gathered || !image || !width || !height || !tile_w || !tile_h || !n_ranks)
-        return fail(c, RT_ERR_INVALID, "rt_assemble_tiles: NULL or zero argument");
+        return fail(c, RT_ERR_INVALID, "%s: NULL or zero argument", who);
     if (!is_device_ptr(gathered) || !is_device_ptr(image))
-        return fail(c, RT_ERR_INVALID, "rt_assemble_tiles: both buffers must be device memory");
+        return fail(c, RT_ERR_INVALID, "%s: both buffers must be device memory", who);
     const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
     const size_t min_stride = (size_t)((tiles_x * tiles_y + n_ranks - 1) / n_ranks) * tile_w * tile_h;
     const size_t per_rank = rank_stride ? rank_stride : min_stride;
-    if (per_rank < min_stride) return fail(c, RT_ERR_INVALID, "rt_assemble_tiles: rank_stride smaller than one rank's block");
-    hipLaunchKernelGGL(k_assemble, dim3((width + 255) / 256, height), dim3(256), 0, c->stream,
-                       reinterpret_cast<const uint2*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks,
-                       per_rank, reinterpret_cast<uint2*>(image));
+    if (per_rank < min_stride) return fail(c, RT_ERR_INVALID, "%s: rank_stride smaller than one rank's block", who);
+    hipLaunchKernelGGL(k_assemble<PIXEL>, dim3((width + 255) / 256, height), dim3(256), 0, c->stream,
+                       reinterpret_cast<const PIXEL*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks, per_rank,
+                       reinterpret_cast<PIXEL*>(image));
     RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_assemble_tiles(rt_ctx* c, const rt_hit* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+                                 uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, rt_hit* image) {
+    return assemble_tiles<uint2>(c, gathered, width, height, tile_w, tile_h, n_ranks, rank_stride, image, "rt_assemble_tiles");
+}
+
+extern "C" int rt_assemble_tiles_rgba8(rt_ctx* c, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+                                       uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, uint8_t* image) {
+    return assemble_tiles<uint32_t>(c, gathered, width, height, tile_w, tile_h, n_ranks, rank_stride, image,
+                                    "rt_assemble_tiles_rgba8");
+}
+
+// ================================================================== shaded picture
+
+extern "C" int rt_set_materials(rt_ctx* c, const MaterialData* materials, uint32_t n) {
+    if (int r = use(c)) return r;
+    if (n && !materials) return fail(c, RT_ERR_INVALID, "rt_set_materials: NULL array with non-zero count");
+    if (int r = scene_barrier(c)) return r;
+    RT_HIP(c, c->materials.reserve((size_t)n * sizeof(MaterialData) + 16));
+    if (n) RT_HIP(c, hipMemcpyAsync(c->materials.p, materials, (size_t)n * sizeof(MaterialData), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->n_materials = n;
+    return RT_OK;
+}
+
+extern "C" void rt_default_render_opts(rt_render_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->max_bounces = 8;  // MAX_BOUNCES, raytracer_unified.wgsl:656
+}
+
+extern "C" int rt_render(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height, const rt_shard* shard,
+                         const rt_render_opts* opts, uint8_t* out_rgba8) {
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_render: no grid (call rt_build_grid or rt_set_grid_*)");
+    if (!cam || !out_rgba8) return fail(c, RT_ERR_INVALID, "rt_render: NULL camera or output");
+    if (!width || !height) return fail(c, RT_ERR_INVALID, "rt_render: empty frame");
+    if (shard && (!shard->tile_w || !shard->tile_h || !shard->stride))
+        return fail(c, RT_ERR_INVALID, "rt_render: shard tile size and stride must be non-zero");
+    rt_render_opts o;
+    rt_default_render_opts(&o);
+    if (opts) o = *opts;
+    const ShardMap m = make_shard(width, height, shard);
+    const size_t n_out = (size_t)m.n_local * m.tile_w * m.tile_h;
+    if (n_out == 0) return RT_OK;
+    const uint64_t blocks = (uint64_t)m.n_local * ((m.sub_x + 1) / 2) * ((m.sub_y + 1) / 2);
+    if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "rt_render: frame too large");
+    const bool host_out = !is_device_ptr(out_rgba8);
+    uint32_t* out = reinterpret_cast<uint32_t*>(out_rgba8);
+    if (host_out) {
+        RT_HIP(c, c->out_p.reserve(n_out * sizeof(uint32_t)));
+        out = c->out_p.as<uint32_t>();
+    }
+    if (int r = update_box_frame(c, cam)) return r;
+    const bool stats = c->params.collect_stats != 0;
+    if (stats)
+        if (int r = zero_stats(c)) return r;
+    const DevScene s = make_scene(c);
+    const DevFrame f = make_frame(c, cam, width, height);
+    DevShade sh;
+    memset(&sh, 0, sizeof(sh));
+    sh.boxes = c->boxes.as<float4>();
+    sh.tri_mat = c->tri_mat.as<uint32_t>();
+    sh.materials = c->materials.as<float4>();
+    sh.n_materials = c->n_materials;
+    sh.max_bounces = o.max_bounces;
+    sh.shadows = o.shadows ? 1u : 0u;
+    sh.debug_enabled = o.debug_enabled;
+    sh.debug_x = o.debug_pixel[0];
+    sh.debug_y = o.debug_pixel[1];
+    sh.show_grid = cam->show_grid;
+    unsigned long long* st = stats ? c->stats.as<unsigned long long>() : nullptr;
+    const dim3 grid((uint32_t)blocks);
+    const bool wgsl = c->params.wgsl_compat != 0, has_boxes = s.nb != 0;
+    if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+    else if (wgsl) hipLaunchKernelGGL((k_render<true, false>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+    else if (has_boxes) hipLaunchKernelGGL((k_render<false, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+    else hipLaunchKernelGGL((k_render<false, false>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+    RT_HIP(c, hipGetLastError());
+    if (host_out) RT_HIP(c, hipMemcpyAsync(out_rgba8, out, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (stats) {
+        if (int r = fetch_stats(c)) return r;
+    } else if (host_out) {
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return RT_OK;
 }
 

@@ -60,6 +60,9 @@ struct rt_ctx {
     rt::DevBuf boxes;  // BoxData[nb]
     rt::DevBuf tri_v;  // float[nt*9]: v0,v1,v2
     rt::DevBuf tri_n;  // float4[nt]: geometric normal
+    rt::DevBuf tri_mat;    // u32[nt]: u32(TriangleData::material_id)
+    rt::DevBuf materials;  // MaterialData[n_materials]
+    uint32_t n_materials = 0;
 
     // grid
     bool has_grid = false;

@@ -1,0 +1,130 @@
+// Shaded picture: the rest of the reference's compute shader around trace_ray -
+// sky colour and lighting (src/raytracer_unified.wgsl:590-621), the reflection-bounce loop, the debug-pixel
+// highlight and the texture store of main (:655-720), box colours (:230-233) and the untextured part of the
+// triangle material (:280-303, :345-364).
+//
+// Not here yet: texture sampling, normal maps, emissive textures and the alpha MASK / BLEND rejection inside the
+// triangle test (:286-329). A material that names textures is shaded with its constant factors alone.
+//
+// Same numerics contract as the trace: the reference's f32 expression trees, no contraction, host-evaluated
+// transcendental constants. The 8-bit store is round-to-nearest-even of clamp(c, 0, 1) * 255 (NaN -> 0).
+#pragma once
+
+#include "rt_trace.hpp"
+
+namespace rt {
+
+struct DevShade {
+    const float4* boxes;      // BoxData as six float4: [2] = (color.rgb, reflectivity)
+    const uint32_t* tri_mat;  // material index per triangle: u32(TriangleData::material_id)
+    const float4* materials;  // MaterialData as four float4: (base_color) (emissive, texture) (metallic, roughness, ..) (..)
+    uint32_t n_materials;
+    uint32_t max_bounces;
+    uint32_t shadows;         // 1: a hit whose shadow ray is occluded gets no diffuse light (not in the shader)
+    uint32_t debug_enabled, debug_x, debug_y;
+    float show_grid;
+};
+
+__device__ inline uint32_t unorm8(float c) {
+    float x = fminf(fmaxf(c, 0.0f), 1.0f);  // fmaxf(NaN, 0) = 0
+    return (uint32_t)rintf(x * 255.0f);
+}
+
+// raytracer_unified.wgsl:419-428; WGSL's % on f32 is the truncated remainder (fmodf)
+__device__ inline bool near_grid_boundary(const DevScene& s, V3 pos, float threshold) {
+    const V3 rel = pos - v3(s.bmin[0], s.bmin[1], s.bmin[2]);
+    const float cs = s.cell_size;
+    const V3 local = v3(fmodf(rel.x, cs) / cs, fmodf(rel.y, cs) / cs, fmodf(rel.z, cs) / cs);
+    const float dx = fminf(local.x, 1.0f - local.x), dy = fminf(local.y, 1.0f - local.y), dz = fminf(local.z, 1.0f - local.z);
+    return dx < threshold || dy < threshold || dz < threshold;
+}
+
+template <bool WGSL, bool BOXES>
+__global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
+                                                unsigned long long* stats) {
+    const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
+    const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;
+    const uint32_t blk_per_tile = blk_x * blk_y;
+    const uint32_t lt = blockIdx.x / blk_per_tile, blk = blockIdx.x % blk_per_tile;
+    if (lt >= m.n_local) return;
+    const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
+    const uint32_t lx = sub_x * 8 + (lane & 7), ly = sub_y * 8 + (lane >> 3);
+    const uint32_t tile = m.first + lt * m.stride;
+    const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
+    const bool in_tile = lx < m.tile_w && ly < m.tile_h;
+    const bool live = in_tile && px < f.width && py < f.height;
+
+    uint32_t rgba = 0;
+    Counters ctr{0, 0, 0, 0};
+    unsigned long long n_rays = 0, n_ph = 0, n_sr = 0, n_sh = 0;
+    if (live) {
+        V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+        V3 d = primary_dir(f, px, py);
+        V3 acc = v3(0.0f, 0.0f, 0.0f);
+        float mult = 1.0f;
+        const V3 to_light = f.shadow.d;  // -normalize(LIGHT_DIRECTION)
+        for (uint32_t bounce = 0; bounce < sh.max_bounces; ++bounce) {
+            const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
+            HitRec h;
+            n_rays++;
+            if (!trace_ray<WGSL, false, false, BOXES>(s, o, rd, h, ctr)) {
+                // sky (:591-596)
+                const float t = (d.y + 1.0f) * 0.5f;
+                acc = acc + mix(v3(0.3f, 0.5f, 0.7f), v3(0.5f, 0.7f, 1.0f), t) * mult;
+                break;
+            }
+            if (bounce == 0) n_ph++;
+            const V3 pos = o + d * h.t;
+            const V3 n = hit_normal(s, h, pos);
+            V3 color = v3(0.7f, 0.7f, 0.7f), emissive = v3(0.0f, 0.0f, 0.0f);
+            float refl = 0.0f;
+            if (BOXES && h.ref == MISS) {
+                const float4 c = sh.boxes[6 * h.id + 2];
+                color = v3(c.x, c.y, c.z);
+                refl = c.w;
+            } else {
+                const uint32_t mat = sh.tri_mat[h.id - s.nb];
+                if (mat < sh.n_materials) {
+                    const float4 m0 = sh.materials[4 * mat], m1 = sh.materials[4 * mat + 1], m2 = sh.materials[4 * mat + 2];
+                    color = v3(m0.x, m0.y, m0.z);
+                    emissive = v3(m1.x, m1.y, m1.z);
+                    refl = m2.x;  // metallic (:361)
+                }
+            }
+            // lighting (:598-603)
+            float diffuse = fmaxf(dot(n, to_light), 0.0f);
+            if (sh.shadows) {
+                V3 nf = n;
+                if (dot(nf, d) > 0.0f) nf = neg(nf);
+                HitRec oh;
+                n_rays++;
+                n_sr++;
+                if (trace_ray<WGSL, true, false, BOXES>(s, pos + nf * f.shadow_offset, f.shadow, oh, ctr)) {
+                    n_sh++;
+                    diffuse = 0.0f;
+                }
+            }
+            V3 lit = color * (0.3f + diffuse * 0.7f) + emissive;
+            if (sh.show_grid > 0.5f && near_grid_boundary(s, pos, 0.02f)) lit = mix(lit, v3(0.0f, 1.0f, 0.0f), 0.6f);
+            // bounce loop (:670-688)
+            acc = acc + (lit * (1.0f - refl)) * mult;
+            if (refl < 0.01f) break;
+            mult *= refl;
+            d = d - n * (2.0f * dot(n, d));  // reflect(e1, e2) = e1 - 2 * dot(e2, e1) * e2
+            o = pos + n * 0.001f;
+        }
+        // debug pixel (:693-716)
+        if (sh.debug_enabled) {
+            const int dx = (int)px - (int)sh.debug_x, dy = (int)py - (int)sh.debug_y;
+            if (dx == 0 && dy == 0)
+                acc = v3(1.0f, 1.0f, 0.0f);
+            else if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1)
+                acc = mix(acc, v3(1.0f, 1.0f, 0.0f), 0.5f);
+        }
+        rgba = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xFF000000u;
+    }
+    if (in_tile) out[(size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx] = rgba;
+    if (stats) flush_stats(stats, n_rays, n_ph, n_sr, n_sh, ctr);
+}
+
+}  // namespace rt

@@ -15,7 +15,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import (BOX_DTYPE, HIT_DTYPE, RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES, RT_MISS, TRIANGLE_DTYPE,
+from ._lib import (BOX_DTYPE, HIT_DTYPE, MATERIAL_DTYPE, RtRenderOpts, RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES, RT_MISS, TRIANGLE_DTYPE,
                    CameraUniform, GridMetadata, RayDebugInfo, RtParams, RtShard, RtStats)
 
 DEFAULT_FOV = 0.785398  # raytracer_unified.wgsl:4, src/renderer.rs DEFAULT_FOV
@@ -228,6 +228,30 @@ class TraceCore:
     def assemble_tiles(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride=0):
         self._ck(self._L.rt_assemble_tiles(self._h, _ptr(gathered), width, height, tile_w, tile_h, n_ranks, rank_stride,
                                            _ptr(image)))
+
+    def assemble_tiles_rgba8(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride=0):
+        self._ck(self._L.rt_assemble_tiles_rgba8(self._h, _ptr(gathered), width, height, tile_w, tile_h, n_ranks,
+                                                 rank_stride, _ptr(image)))
+
+    # ---- shaded picture
+    def set_materials(self, materials):
+        m = np.ascontiguousarray(materials if materials is not None else np.zeros(0, MATERIAL_DTYPE), MATERIAL_DTYPE)
+        self._ck(self._L.rt_set_materials(self._h, _ptr(m), len(m)))
+
+    def render(self, cam, width, height, shard=None, max_bounces=8, shadows=False, debug_pixel=None, out=None):
+        """The shader's picture: (n_pixels, 4) uint8 RGBA, row-major (tile-packed with a shard). `out` may be a
+        torch CUDA uint8 tensor / device pointer to keep it on the GPU."""
+        n = shard_pixels(width, height, shard)
+        if out is None:
+            out = np.empty((n, 4), np.uint8)
+        o = RtRenderOpts()
+        self._L.rt_default_render_opts(C.byref(o))
+        o.max_bounces, o.shadows = max_bounces, 1 if shadows else 0
+        if debug_pixel is not None:
+            o.debug_enabled, o.debug_pixel[0], o.debug_pixel[1] = 1, debug_pixel[0], debug_pixel[1]
+        self._ck(self._L.rt_render(self._h, _ref(cam, CameraUniform), width, height, _ref(shard, RtShard), C.byref(o),
+                                   _ptr(out)))
+        return out
 
     def debug_pixel(self, cam, width, height, px, py):
         info = RayDebugInfo()

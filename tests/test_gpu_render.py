@@ -1,0 +1,144 @@
+"""The shaded picture (rt_render) against the CPU oracle, through the C ABI: every byte equal."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+from render_scenes import demo_boxes, demo_materials
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def ocam(ob, cam):
+    o = ob.CameraUniform()
+    C.memmove(C.byref(o), C.byref(cam), C.sizeof(o))
+    return o
+
+
+def oparams(ob, p):
+    return ob.Params.default(**{k: getattr(p, k) for k in ("finest_cell_size", "max_objects_per_cell", "max_dda_steps",
+                                                           "wgsl_compat", "lod_cull", "moving_box_count", "fov",
+                                                           "shadow_offset")})
+
+
+def check(core, ob, scene, cam, w, h, materials=None, what="", **kw):
+    got = core.render(cam, w, h, **kw)
+    okw = dict(kw)
+    if "shard" in okw and okw["shard"] is not None:
+        s = okw["shard"]
+        okw["shard"] = ob.Shard(s.tile_w, s.tile_h, s.first, s.stride)
+    want, st = ob.render(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params), materials=materials, **okw)
+    bad = np.flatnonzero((got != want).any(axis=1))
+    assert bad.size == 0, f"{what}: {bad.size} pixels differ, first {bad[:5]}: {got[bad[:5]]} vs {want[bad[:5]]}"
+    return want, st
+
+
+def test_committed_pictures(core, ob, rt, car_xyz9):
+    g = np.load(os.path.join(HERE, "golden", "render_golden.npz"))
+    tris = ob.pyramid_triangles()
+    tris["material_id"] = [0, 1, 2, 7, 0, 1]
+    core.set_scene(None, tris)
+    core.set_materials(demo_materials(ob))
+    core.build_grid(cell_size=1.0)
+    cam = rt.Camera.for_scene("pyramid").to_uniform(0.0, 36.0)
+    assert np.array_equal(core.render(cam, 64, 36), g["pyramid_rgba"])
+    core.set_materials(None)
+    core.set_scene(None, rt.triangles_from_xyz9(car_xyz9))
+    core.build_grid()
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, 36.0)
+    assert np.array_equal(core.render(cam, 64, 36), g["car_rgba"])
+    assert np.array_equal(core.render(cam, 64, 36, shadows=True), g["car_rgba_shadows"])
+    core.set_scene(demo_boxes(ob), None)
+    core.build_grid(cell_size=4.0)
+    cam = rt.Camera((4, 12, 40), math.pi, -0.25).to_uniform(0.4, 54.0)
+    assert np.array_equal(core.render(cam, 96, 54), g["boxes_rgba"])
+
+
+@pytest.mark.parametrize("w,h", [(160, 90), (1920, 1080)])
+def test_car(core, ob, rt, car_xyz9, w, h):
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    core.set_scene(None, tris)
+    core.set_materials(None)
+    core.build_grid()
+    scene = ob.Scene(None, tris)
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+    check(core, ob, scene, cam, w, h, what="car")
+    _, st = check(core, ob, scene, cam, w, h, shadows=True, what="car shadows")
+    assert st["shadow_hits"] > 0
+
+
+def test_materials_and_reflections(core, ob, rt, car_xyz9):
+    """Metallic materials on the car: up to eight bounces per pixel (raytracer_unified.wgsl:655-688)."""
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    tris["material_id"] = np.arange(len(tris)) % 5  # 3 and 4 are out of range -> grey
+    mats = demo_materials(ob)
+    mats["metallic"] = [0.3, 0.0, 0.85]
+    core.set_scene(None, tris)
+    core.set_materials(mats)
+    core.build_grid()
+    scene = ob.Scene(None, tris)
+    for pos, yaw, pitch in (((200, 200, 300), 3.35, -0.28), ((0, 150, 50), 1.0, -0.4)):
+        cam = rt.Camera(pos, yaw, pitch).to_uniform(0.0, 135.0)
+        _, st = check(core, ob, scene, cam, 240, 135, materials=mats, what=f"materials from {pos}")
+        assert st["rays"] > 240 * 135 * 1.1
+        check(core, ob, scene, cam, 240, 135, materials=mats, shadows=True, max_bounces=3, what="materials, shadows, 3 bounces")
+    core.set_materials(None)
+
+
+def test_boxes_moving_mirror_overlay_debug(core, ob, rt):
+    boxes = demo_boxes(ob)
+    core.set_scene(boxes, None)
+    core.build_grid(cell_size=4.0)
+    scene = ob.Scene(boxes, None, cell_size=4.0)
+    for time in (0.0, 0.4, 2.2):
+        cam = rt.Camera((4, 12, 40), math.pi, -0.25).to_uniform(time, 108.0)
+        _, st = check(core, ob, scene, cam, 192, 108, what=f"boxes t={time}")
+        assert st["rays"] > 192 * 108 * 1.2
+    cam = rt.Camera((4, 12, 40), math.pi, -0.25).to_uniform(0.4, 108.0, show_grid=True)
+    check(core, ob, scene, cam, 192, 108, what="grid overlay")
+    check(core, ob, scene, cam, 192, 108, debug_pixel=(100, 60), what="debug pixel")
+    check(core, ob, scene, cam, 192, 108, debug_pixel=(0, 0), shadows=True, max_bounces=2, what="debug corner")
+
+
+def test_mixed_scene_both_constant_sets(rt, ob):
+    from test_gpu_parity import random_boxes
+    for wgsl in (0, 1):
+        core = rt.TraceCore(0, rt.default_params(wgsl_compat=wgsl))
+        boxes = random_boxes(ob, 40, 11, extent=45.0, moving_last=3)
+        boxes["reflectivity"] = np.linspace(0.0, 0.9, len(boxes), dtype=np.float32)
+        boxes["color"] = np.random.default_rng(2).uniform(0, 1, (len(boxes), 3)).astype(np.float32)
+        tris = ob.generate_test_triangles(3000)
+        tris["material_id"] = np.arange(len(tris)) % 4
+        mats = demo_materials(ob)
+        core.set_scene(boxes, tris)
+        core.set_materials(mats)
+        core.build_grid(cell_size=8.0)
+        scene = ob.Scene(boxes, tris, cell_size=8.0)
+        cam = rt.Camera((10, 30, 140), math.pi, -0.2).to_uniform(0.6, 90.0)
+        check(core, ob, scene, cam, 160, 90, materials=mats, what=f"mixed wgsl={wgsl}")
+        core.close()
+
+
+def test_shards_device_output_and_assembly(core, ob, rt, car_xyz9):
+    import torch
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    core.set_scene(None, tris)
+    core.set_materials(None)
+    core.build_grid()
+    scene = ob.Scene(None, tris)
+    w, h, tw, th, n = 300, 170, 64, 64, 3
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+    full, _ = check(core, ob, scene, cam, w, h, shadows=True, what="full")
+    per_rank = max(rt.shard_pixels(w, h, rt.RtShard(tw, th, r, n)) for r in range(n))
+    gathered = torch.zeros((n, per_rank, 4), dtype=torch.uint8, device="cuda")
+    for r in range(n):
+        shard = rt.RtShard(tw, th, r, n)
+        check(core, ob, scene, cam, w, h, shadows=True, shard=shard, what=f"shard {r}")
+        core.render(cam, w, h, shard=shard, shadows=True, out=gathered[r])
+    image = torch.empty((h * w, 4), dtype=torch.uint8, device="cuda")
+    core.assemble_tiles_rgba8(gathered, w, h, tw, th, n, image, rank_stride=per_rank)
+    core.sync()
+    assert np.array_equal(image.cpu().numpy(), full)

@@ -9,8 +9,9 @@ hit, all inside one kernel launch, with scene, grid and output buffers resident 
 with a two-image swap chain, consecutive frames go to two streams with their own output buffers (two frames in
 flight): a frame's last waves - a few pixel blocks over the model's densest cells, one long dependent chain
 each - then overlap the next frame's bulk instead of leaving the GPU idle. At N > 1
-the SAME frame is cut into 64x64 tiles dealt round-robin to the ranks and gathered on rank 0
-(total work fixed: strong scaling). Prints one JSON line on rank 0.
+the SAME frame is cut into 64x64 tiles dealt round-robin to the ranks, each rank shades its tiles (same
+primary + shadow rays) and the RGBA8 framebuffer is gathered on rank 0 by RCCL (total work fixed: strong
+scaling; 4 bytes per pixel cross the links instead of 16 for hit records). Prints one JSON line on rank 0.
 
 The frame's work (cells visited, candidates tested, rays) is counted by the kernel's own counters in an
 untimed launch. The CPU oracle is used for one thing only, outside the timed region: the `cpu_baseline`
@@ -103,11 +104,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # Rehearsal on a one-GPU box: RT_BENCH_ONE_GPU=1 puts every rank on GPU 0 and uses gloo (RCCL refuses two
+    # ranks on one device). Never set by the driver.
+    rehearsal = os.environ.get("RT_BENCH_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     xyz9 = np.load(os.path.join(ROOT, "tests", "golden", "car_tris.npy"))
     tris = rt.triangles_from_xyz9(xyz9) if rank == 0 else None
@@ -140,7 +149,9 @@ def main():
         def sync():
             core.sync()
     else:
-        sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True)
+        # the framebuffer that travels is the shaded RGBA8 picture; one bounce = the same primary + shadow rays
+        sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
+                                   frames_in_flight=FRAMES_IN_FLIGHT, max_bounces=1)
 
         def step():
             sh.trace(cam)
@@ -193,7 +204,9 @@ def main():
                        "width": WIDTH, "height": HEIGHT, "rays_per_frame": rays_per_frame,
                        "primary_hits": stats["primary_hits"], "grid": list(meta.fine_dims), "cell_size": 16.0,
                        "cells": n_cells, "cell_refs": n_refs,
-                       "frames_in_flight": FRAMES_IN_FLIGHT if world == 1 else 1,
+                       "frames_in_flight": FRAMES_IN_FLIGHT,
+                       "output": "rt_hit records, 16 B per pixel, resident in HBM" if world == 1 else
+                                 "shaded RGBA8 picture (ambient + diffuse with the shadow-ray term), 4 B per pixel, gathered on rank 0",
                        "parallelism": "single GPU" if world == 1 else f"{TILE}x{TILE} tiles round-robin over {world} GPUs, RCCL gather to rank 0"},
         }
         if world == 1:

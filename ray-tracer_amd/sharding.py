@@ -9,12 +9,15 @@ frame shards without any data-path exchange until the end:
             deterministic, so all ranks hold identical cell lists without shipping them
   tiles     the frame is cut into tile_w x tile_h tiles dealt round-robin: rank r traces tiles
             r, r+N, r+2N, ... (sky tiles are cheap, dense tiles expensive: interleaving balances)
-  gather    every rank's packed hit records go to rank 0 in ONE gather (primary and shadow blocks
-            travel together); on xGMI that is seven point-to-point transfers into rank 0 over
-            seven separate links, no ring
-  assemble  rank 0 scatters the gathered tiles into the row-major frame (rt_assemble_tiles)
+  gather    every rank's packed tiles go to rank 0 in ONE gather; on xGMI that is seven point-to-point
+            transfers into rank 0 over seven separate links, no ring. What travels is either the
+            shaded RGBA8 picture (4 bytes per pixel) or the hit records (16 bytes per pixel with
+            shadow records); the links into rank 0 carry (N-1)/N of a frame, so the byte count per
+            pixel decides how many frames per second N GPUs can deliver
+  assemble  rank 0 scatters the gathered tiles into the row-major frame (rt_assemble_tiles[_rgba8])
 
-No step synchronises the host: calls are queued on the process's current torch stream.
+No step synchronises the host. Frames can be kept in flight (separate streams and buffers per frame), which
+overlaps a frame's gather, and the long tail of its trace kernel, with the next frame's tracing.
 The tracer is passed in (`core`): the product passes a ray_tracer_amd.TraceCore; the CPU tests pass
 a stand-in so the sharding logic runs under gloo without a GPU.
 """
@@ -57,59 +60,99 @@ def broadcast_scene(boxes, tris, device, src=0):
     return b, t
 
 
-class FrameSharder:
-    """Traces this rank's tiles of a frame and gathers the frame on rank 0."""
+class _Slot:
+    """Buffers and stream of one frame in flight."""
 
-    def __init__(self, core, width, height, tile_w=64, tile_h=64, rank=None, world=None, device="cuda", shadow=True):
+    def __init__(self, sharder, device):
+        s = sharder
+        self.stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
+        if s.mode == "rgba":
+            # [record][r, g, b, a]; tiles this rank does not own stay zero
+            self.local = torch.zeros((s.per_rank, 4), dtype=torch.uint8, device=device)
+        else:
+            # [block (primary, shadow)][record][id, t-bits]; tiles this rank does not own stay "miss"
+            self.local = torch.full((s.blocks, s.per_rank, 2), -1, dtype=torch.int32, device=device)
+        self.packed = self.gathered = self.image = None
+        if s.rank == 0:
+            # the gather writes rank r's block straight into packed[r]
+            self.packed = torch.empty((s.world,) + tuple(self.local.shape), dtype=self.local.dtype, device=device)
+            self.gathered = [self.packed[r] for r in range(s.world)]
+            if s.mode == "rgba":
+                self.image = torch.empty((s.height * s.width, 4), dtype=torch.uint8, device=device)
+            else:
+                self.image = torch.empty((s.blocks, s.height * s.width, 2), dtype=torch.int32, device=device)
+
+
+class FrameSharder:
+    """Traces this rank's tiles of a frame and gathers the frame on rank 0.
+
+    mode "hits": rt_hit records, primary (and shadow) blocks, 8 (16) bytes per pixel on the wire.
+    mode "rgba": the shaded picture of TraceCore.render, 4 bytes per pixel on the wire - the framebuffer proper;
+                 with shadow=True the lighting includes the shadow-ray term, so the rays traced are the same
+                 primary + shadow set as in "hits" mode (max_bounces bounds the reflection rays on top).
+    frames_in_flight: consecutive frames use separate streams and buffers, so a rank traces frame k+1 while frame
+                 k is on the links and while the last waves of frame k drain. The images returned for a frame stay
+                 valid until that many further frames have been started."""
+
+    def __init__(self, core, width, height, tile_w=64, tile_h=64, rank=None, world=None, device="cuda", shadow=True,
+                 mode="hits", frames_in_flight=1, max_bounces=8):
+        if mode not in ("hits", "rgba"):
+            raise ValueError("mode must be 'hits' or 'rgba'")
         self.core, self.width, self.height, self.tile_w, self.tile_h = core, width, height, tile_w, tile_h
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
-        self.shadow = shadow
+        self.shadow, self.mode, self.max_bounces = shadow, mode, max_bounces
         self.device = device
-        # Trace kernels, the gather and the assemble kernel must share one in-order stream: the collective
-        # only waits for work queued on torch's current stream.
-        self.stream = None
-        if torch.device(device).type == "cuda":
-            self.stream = torch.cuda.Stream(device)
-            core.set_stream(self.stream.cuda_stream)
         self.shard = RtShard(tile_w, tile_h, self.rank, self.world)
         self.per_rank = per_rank_pixels(width, height, tile_w, tile_h, self.world)
         self.blocks = 2 if shadow else 1
-        # [block (primary, shadow)][record][id, t-bits]; tiles this rank does not own stay "miss"
-        self.local = torch.full((self.blocks, self.per_rank, 2), -1, dtype=torch.int32, device=device)
-        if self.rank == 0:
-            # the gather writes rank r's [primary | shadow] block straight into packed[r]
-            self.packed = torch.empty((self.world, self.blocks, self.per_rank, 2), dtype=torch.int32, device=device)
-            self.gathered = [self.packed[r] for r in range(self.world)]
-            self.image = torch.empty((self.blocks, height * width, 2), dtype=torch.int32, device=device)
+        # Trace kernels, the gather and the assemble kernel of a frame share one in-order stream: the collective
+        # only waits for work queued on torch's current stream, and makes that stream wait for its completion.
+        self.slots = [_Slot(self, device) for _ in range(max(1, frames_in_flight))]
+        self.frame = 0
+        self.local, self.packed, self.image = self.slots[0].local, self.slots[0].packed, self.slots[0].image
+
+    def _local(self, cam, slot):
+        if self.mode == "rgba":
+            self.core.render(cam, self.width, self.height, shard=self.shard, max_bounces=self.max_bounces,
+                             shadows=self.shadow, out=slot.local)
         else:
-            self.gathered = self.packed = self.image = None
+            self.core.trace_primary(cam, self.width, self.height, shard=self.shard, shadow=self.shadow,
+                                    out_primary=slot.local[0], out_shadow=slot.local[1] if self.shadow else None)
+        return slot.local
 
     def trace_local(self, cam):
         """This rank's tiles only (no communication): the per-GPU share of the frame."""
-        self.core.trace_primary(cam, self.width, self.height, shard=self.shard, shadow=self.shadow,
-                                out_primary=self.local[0], out_shadow=self.local[1] if self.shadow else None)
-        return self.local
+        return self._local(cam, self.slots[0])
 
     def trace(self, cam):
-        """One frame. Returns [primary, shadow] images (height*width, 2) int32 on rank 0, None elsewhere."""
-        if self.stream is not None:
-            with torch.cuda.stream(self.stream):
-                return self._trace(cam)
-        return self._trace(cam)
+        """One frame. On rank 0 returns [primary, shadow] images (height*width, 2) int32 in "hits" mode, the
+        (height*width, 4) uint8 picture in "rgba" mode; None on the other ranks."""
+        slot = self.slots[self.frame % len(self.slots)]
+        self.frame += 1
+        if slot.stream is not None:
+            self.core.set_stream(slot.stream.cuda_stream)
+            with torch.cuda.stream(slot.stream):
+                return self._trace(cam, slot)
+        return self._trace(cam, slot)
 
     def synchronize(self):
-        if self.stream is not None:
-            self.stream.synchronize()
+        for slot in self.slots:
+            if slot.stream is not None:
+                slot.stream.synchronize()
 
-    def _trace(self, cam):
-        self.trace_local(cam)
+    def _trace(self, cam, slot):
+        self._local(cam, slot)
         if self.world > 1:
-            dist.gather(self.local, self.gathered, dst=0)
+            dist.gather(slot.local, slot.gathered, dst=0)
         if self.rank != 0:
             return None
-        src = self.packed if self.world > 1 else self.local.unsqueeze(0)
+        src = slot.packed if self.world > 1 else slot.local.unsqueeze(0)
+        if self.mode == "rgba":
+            self.core.assemble_tiles_rgba8(src[0], self.width, self.height, self.tile_w, self.tile_h, self.world,
+                                           slot.image, rank_stride=self.per_rank)
+            return slot.image
         for b in range(self.blocks):
             self.core.assemble_tiles(src[0, b], self.width, self.height, self.tile_w, self.tile_h, self.world,
-                                     self.image[b], rank_stride=self.blocks * self.per_rank)
-        return [self.image[b] for b in range(self.blocks)]
+                                     slot.image[b], rank_stride=self.blocks * self.per_rank)
+        return [slot.image[b] for b in range(self.blocks)]

@@ -142,3 +142,35 @@ def test_shards_device_output_and_assembly(core, ob, rt, car_xyz9):
     core.assemble_tiles_rgba8(gathered, w, h, tw, th, n, image, rank_stride=per_rank)
     core.sync()
     assert np.array_equal(image.cpu().numpy(), full)
+
+
+def test_frame_sharder_on_the_gpu_single_rank(core, ob, rt, car_xyz9):
+    """The multi-GPU driver with world size 1 (no collective): tile packing, per-frame streams and buffers,
+    RGBA and hit-record modes, through the real kernels."""
+    from ray_tracer_amd import sharding
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    core.set_scene(None, tris)
+    core.set_materials(None)
+    core.build_grid()
+    scene = ob.Scene(None, tris)
+    w, h = 300, 170
+    cams = [rt.Camera(p, y, pi).to_uniform(0.0, float(h)) for p, y, pi in
+            (((200, 200, 300), 3.35, -0.28), ((0, 150, 50), 1.0, -0.4), ((-400, 50, -500), 0.7, 0.0))]
+    sh = sharding.FrameSharder(core, w, h, 64, 64, rank=0, world=1, device="cuda", shadow=True, mode="rgba",
+                               frames_in_flight=2, max_bounces=1)
+    pics = [sh.trace(c) for c in cams]
+    sh.synchronize()
+    for k in (1, 2):  # frame 0's buffers were reused by frame 2
+        want, _ = ob.render(scene, ocam(ob, cams[k]), w, h, max_bounces=1, shadows=True)
+        assert np.array_equal(pics[k].cpu().numpy(), want), f"rgba frame {k}"
+    sh = sharding.FrameSharder(core, w, h, 64, 64, rank=0, world=1, device="cuda", shadow=True, mode="hits",
+                               frames_in_flight=3)
+    outs = [sh.trace(c) for c in cams]
+    sh.synchronize()
+    core.set_stream(None)
+    for k, c in enumerate(cams):
+        wp, ws, _ = ob.trace_primary(scene, ocam(ob, c), w, h)
+        gp = outs[k][0].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
+        gs = outs[k][1].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
+        assert np.array_equal(gp["id"], wp["id"]) and np.array_equal(gp["t"].view(np.uint32), wp["t"].view(np.uint32))
+        assert np.array_equal(gs["id"], ws["id"]) and np.array_equal(gs["t"].view(np.uint32), ws["t"].view(np.uint32))

@@ -29,12 +29,27 @@ class OracleCore:
         if shadow:
             out_shadow[:len(s)] = torch.from_numpy(s.view(np.int32).reshape(-1, 2))
 
+    def render(self, cam, width, height, shard=None, max_bounces=8, shadows=False, out=None):
+        osh = self.ob.Shard(shard.tile_w, shard.tile_h, shard.first, shard.stride) if shard is not None else None
+        img, _ = self.ob.render(self.scene, cam, width, height, shard=osh, max_bounces=max_bounces, shadows=shadows,
+                                n_threads=2)
+        out[:len(img)] = torch.from_numpy(img)
+
+    def set_stream(self, stream):
+        pass
+
+    def assemble_tiles_rgba8(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride=0):
+        self._assemble(gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride, torch.uint8, 4)
+
     def assemble_tiles(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride=0):
+        self._assemble(gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride, torch.int32, 2)
+
+    def _assemble(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride, dtype, per):
         # `gathered` is a view starting at rank 0's block; ranks are rank_stride records apart
         tiles_x = -(-width // tile_w)
         base = gathered.untyped_storage()
-        flat = torch.empty(0, dtype=torch.int32).set_(base).view(-1, 2)
-        off = gathered.storage_offset() // 2
+        flat = torch.empty(0, dtype=dtype).set_(base).view(-1, per)
+        off = gathered.storage_offset() // per
         for y in range(height):
             for x in range(width):
                 tile = (y // tile_h) * tiles_x + x // tile_w
@@ -70,6 +85,18 @@ def _worker(rank, world, port, tmp):
             open(os.path.join(tmp, "result"), "w").write(f"{int(ok)} {hits}")
         else:
             assert out is None
+        # the shaded picture, two frames in flight (buffers alternate), second frame from another pose
+        shr = sharding.FrameSharder(OracleCore(ob, scene), W, H, TW, TH, device="cpu", shadow=True, mode="rgba",
+                                    frames_in_flight=2, max_bounces=2)
+        cam2 = ob.camera_to_uniform((0, 150, 50), 1.0, -0.4, 0.0, float(H))
+        pics = [shr.trace(c) for c in (cam, cam2, cam)]
+        if rank == 0:
+            ok2 = True
+            for c, pic in ((cam2, pics[1]), (cam, pics[2])):  # pics[0]'s buffer has been reused by the third frame
+                want, _ = ob.render(scene, c, W, H, max_bounces=2, shadows=True, n_threads=2)
+                ok2 = ok2 and np.array_equal(pic.numpy(), want)
+            ok2 = ok2 and pics[0] is pics[2] and pics[0] is not pics[1]
+            open(os.path.join(tmp, "result_rgba"), "w").write(str(int(ok2)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -86,6 +113,7 @@ def test_frame_sharding_two_ranks_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     ok, hits = open(tmp_path / "result").read().split()
     assert ok == "1" and int(hits) > 1000
+    assert open(tmp_path / "result_rgba").read() == "1"
 
 
 def test_tile_bookkeeping():

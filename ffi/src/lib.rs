@@ -39,7 +39,17 @@ extern "C" {
                             out_primary: *mut RtHit, out_shadow: *mut RtHit) -> c_int;
     pub fn rt_trace_rays(ctx: *mut RtCtx, camera: *const c_void, origins: *const f32, dirs: *const f32, n: u32,
                          out: *mut RtHit, any_hit: c_int) -> c_int;
+    pub fn rt_set_stream(ctx: *mut RtCtx, hip_stream: *mut c_void) -> c_int;
+    pub fn rt_set_materials(ctx: *mut RtCtx, materials: *const c_void, n: u32) -> c_int;
+    pub fn rt_default_render_opts(o: *mut RtRenderOpts);
+    pub fn rt_render(ctx: *mut RtCtx, camera: *const c_void, width: u32, height: u32, shard: *const RtShard,
+                     opts: *const RtRenderOpts, out_rgba8: *mut u8) -> c_int;
 }
+
+/// `rt_render_opts` of include/rt_mi355.h.
+#[repr(C)]
+#[derive(Copy, Clone, Default)]
+pub struct RtRenderOpts { pub max_bounces: u32, pub shadows: u32, pub debug_enabled: u32, pub debug_pixel: [u32; 2], pub _pad: [u32; 3] }
 
 /// Owns one context. `Send` but not `Sync`: the C side is not re-entrant (one in-order stream).
 pub struct TraceCore { ctx: *mut RtCtx }
@@ -71,6 +81,21 @@ impl TraceCore {
         self.check(unsafe { rt_trace_primary(self.ctx, camera.as_ptr().cast(), width, height, std::ptr::null(),
                                              p.as_mut_ptr(), s.as_mut_ptr()) })?;
         Ok((p, s))
+    }
+}
+
+impl TraceCore {
+    /// `Vec<MaterialData>` bytes (src/types.rs:248-261), the renderer's "Materials" buffer.
+    pub fn set_materials(&mut self, materials: &[u8]) -> Result<(), String> {
+        self.check(unsafe { rt_set_materials(self.ctx, materials.as_ptr() as *const c_void, (materials.len() / 64) as u32) })
+    }
+
+    /// The Rgba8Unorm picture `ComputeState::render` returns (src/core/ray_tracing_layer.rs:436-493).
+    pub fn render(&self, camera: &[u8], width: u32, height: u32) -> Result<Vec<u8>, String> {
+        let mut rgba = vec![0u8; width as usize * height as usize * 4];
+        self.check(unsafe { rt_render(self.ctx, camera.as_ptr() as *const c_void, width, height, std::ptr::null(),
+                                      std::ptr::null(), rgba.as_mut_ptr()) })?;
+        Ok(rgba)
     }
 }
 

@@ -84,6 +84,20 @@ public:
         return f;
     }
 
+    // The bytes ComputeState::render returns (src/core/ray_tracing_layer.rs:436-493): the shader's Rgba8Unorm
+    // picture, width * height * 4, row-major.
+    std::vector<uint8_t> render_rgba(const Camera& camera, float time, const rt_render_opts* opts = nullptr) const {
+        const CameraUniform u = camera.to_uniform(time, (float)height_, params_.fov, false);
+        std::vector<uint8_t> rgba((size_t)width_ * height_ * 4);
+        check(rt_render(ctx_, &u, width_, height_, nullptr, opts, rgba.data()));
+        return rgba;
+    }
+
+    // The "Materials" storage buffer (src/renderer.rs:147-156).
+    void set_materials(const std::vector<MaterialData>& materials) {
+        check(rt_set_materials(ctx_, materials.data(), (uint32_t)materials.size()));
+    }
+
     GridMetadata grid_metadata() const {
         GridMetadata m;
         check(rt_get_grid(ctx_, &m, nullptr, nullptr));

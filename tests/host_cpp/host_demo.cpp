@@ -31,6 +31,9 @@ int main(int argc, char** argv) {
             if (!fp) return 3;
             fwrite(f.primary.data(), sizeof(rt_hit), f.primary.size(), fp);
             fwrite(f.shadow.data(), sizeof(rt_hit), f.shadow.size(), fp);
+            // the shaded picture, as ComputeState::render hands it out
+            const std::vector<uint8_t> rgba = tracer.render_rgba(rt_host::Camera::for_scene("pyramid"), 0.0f);
+            fwrite(rgba.data(), 1, rgba.size(), fp);
             fclose(fp);
         }
     } catch (const std::exception& e) {

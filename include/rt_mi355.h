@@ -207,7 +207,12 @@ void rt_default_render_opts(rt_render_opts* o);
 
 /* Replaces the "Materials" storage buffer (src/renderer.rs:147-156): MaterialData records
  * indexed by TriangleData::material_id. Without it every triangle is the shader's grey
- * (wgsl:366-370). Textures, normal maps and the alpha modes are not evaluated yet. */
+ * (wgsl:366-370). Evaluated: base colour, emissive, metallic (= reflectivity), and the alpha
+ * rules of the triangle test for materials without a base-colour texture (MASK below
+ * alpha_cutoff / BLEND below 0.01 discard every hit, wgsl:310-321) - those triangles become
+ * invisible to rt_trace_primary, rt_trace_rays and rt_render alike, whether the materials
+ * arrive before or after the grid. Not evaluated yet: texture sampling (a textured material
+ * keeps its triangles visible and is shaded with its constant factors), normal maps. */
 int rt_set_materials(rt_ctx* ctx, const MaterialData* materials, uint32_t n);
 
 /* Replaces dispatch_workgroups + the Rgba8Unorm output texture (src/renderer.rs:822-868,

@@ -88,7 +88,8 @@ class RayDebugInfo(C.Structure):
 
 class _Scene(C.Structure):
     _fields_ = [("boxes", C.c_void_p), ("nb", C.c_uint32), ("tris", C.c_void_p), ("nt", C.c_uint32),
-                ("meta", GridMetadata), ("cell_start", C.c_void_p), ("indices", C.c_void_p), ("n_cells", C.c_uint64)]
+                ("meta", GridMetadata), ("cell_start", C.c_void_p), ("indices", C.c_void_p), ("n_cells", C.c_uint64),
+                ("mats", C.c_void_p), ("n_mats", C.c_uint32)]
 
 
 def build(force=False):
@@ -395,8 +396,9 @@ class Grid:
 class Scene:
     """What a trace call needs: objects + grid (the oracle's view of the bind group)."""
 
-    def __init__(self, boxes, tris, grid=None, **grid_kw):
+    def __init__(self, boxes, tris, grid=None, materials=None, **grid_kw):
         self.grid = grid if grid is not None else Grid(boxes, tris, **grid_kw)
+        self.materials = _c(materials, MATERIAL_DTYPE) if materials is not None else None
         self.boxes, self.tris = self.grid.boxes, self.grid.tris
         s = _Scene()
         s.boxes, s.nb = self.boxes.ctypes.data, len(self.boxes)
@@ -404,6 +406,8 @@ class Scene:
         s.meta = self.grid.meta
         s.cell_start, s.indices = self.grid.cell_start.ctypes.data, self.grid.indices.ctypes.data
         s.n_cells = self.grid.n_cells
+        if self.materials is not None and len(self.materials):
+            s.mats, s.n_mats = self.materials.ctypes.data, len(self.materials)
         self._s = s
 
 
@@ -437,6 +441,8 @@ def render(scene, cam, width, height, params=None, shard=None, materials=None, m
     n_threads = n_threads or os.cpu_count() or 1
     n = shard_pixels(width, height, shard)
     out = np.empty((n, 4), np.uint8)
+    if materials is None:
+        materials = scene.materials
     mats = _c(materials if materials is not None else np.zeros(0, MATERIAL_DTYPE), MATERIAL_DTYPE)
     o = RenderOpts()
     o.max_bounces, o.shadows = max_bounces, 1 if shadows else 0

@@ -587,6 +587,19 @@ inline void world_to_cell_u(V3 pos, V3 bmin, float cell, uint32_t out[3]) {
 
 inline V3 clamp3(V3 v, V3 lo, V3 hi) { return vmin(vmax(v, lo), hi); }
 
+// Alpha rules inside the shader's triangle test (raytracer_unified.wgsl:280-321) for materials without a
+// base-colour texture: MASK discards the hit when base_color.a < alpha_cutoff, BLEND when base_color.a < 0.01.
+inline bool alpha_discards(const orc_scene& s, const TriangleData& tr) {
+    if (!s.mats) return false;
+    uint32_t mat = f2u_sat(tr.material_id);
+    if (mat >= s.n_mats) return false;
+    const MaterialData& m = s.mats[mat];
+    if (m.texture_index >= 0) return false;
+    if (m.alpha_mode == 1u) return m.base_color[3] < m.alpha_cutoff;
+    if (m.alpha_mode == 2u) return m.base_color[3] < 0.01f;
+    return false;
+}
+
 // raytracer_unified.wgsl:430-588, geometry only. any_hit: stop at the first accepted intersection.
 Hit trace_ray(const orc_scene& s, const rt_params& p, const CameraUniform& cam, const FrameConsts& fc, V3 o, V3 d,
               bool any_hit, Counters& ctr) {
@@ -678,7 +691,7 @@ Hit trace_ray(const orc_scene& s, const rt_params& p, const CameraUniform& cam, 
                     ctr.tri++;
                     const TriangleData& tr = s.tris[ti];
                     TriHit th;
-                    if (moller_trumbore(o, d, ld(tr.v0), ld(tr.v1), ld(tr.v2), wgsl, &th)) {
+                    if (moller_trumbore(o, d, ld(tr.v0), ld(tr.v1), ld(tr.v2), wgsl, &th) && !alpha_discards(s, tr)) {
                         Hit h;
                         h.hit = true;
                         h.t = th.t;
@@ -1033,7 +1046,7 @@ extern "C" void orc_trace_rays_bruteforce(const orc_scene* s, const rt_params* p
             for (uint32_t k = 0; k < s->nt; ++k) {
                 const TriangleData& tr = s->tris[k];
                 TriHit th;
-                if (moller_trumbore(o, d, ld(tr.v0), ld(tr.v1), ld(tr.v2), wgsl, &th) && th.t < best) {
+                if (moller_trumbore(o, d, ld(tr.v0), ld(tr.v1), ld(tr.v2), wgsl, &th) && th.t < best && !alpha_discards(*s, tr)) {
                     best = th.t;
                     id = s->nb + k;
                 }

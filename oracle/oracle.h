@@ -88,6 +88,8 @@ typedef struct orc_scene {
     const uint32_t* cell_start; /* n_cells + 1 */
     const uint32_t* indices;
     uint64_t n_cells;
+    const MaterialData* mats; /* may be NULL: the "Materials" buffer, for the alpha rules of the triangle test */
+    uint32_t n_mats;
 } orc_scene;
 
 /* Primary (+ optional shadow) rays for the pixels selected by shard (NULL = whole frame);

@@ -38,6 +38,27 @@ __global__ void k_emit_cells(const uint32_t* __restrict__ cell_start, uint32_t g
     cells[p] = rec;
 }
 
+// The id word of every triangle reference, given the materials: a triangle whose material discards all of its
+// hits keeps its record (the shader tests it) but can never be accepted. Only materials without a base-colour
+// texture can be judged here (raytracer_unified.wgsl:291-321); textured ones stay visible.
+__global__ void k_ref_visibility(const uint32_t* __restrict__ indices, uint32_t n_refs, uint32_t nb, uint32_t nt,
+                                 const uint32_t* __restrict__ tri_mat, const float4* __restrict__ materials,
+                                 uint32_t n_materials, float4* __restrict__ refs) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_refs) return;
+    const uint32_t id = indices[r];
+    if (id < nb || id - nb >= nt) return;
+    uint32_t word = id;
+    const uint32_t mat = tri_mat[id - nb];
+    if (mat < n_materials) {
+        const float4 m0 = materials[4 * mat], m1 = materials[4 * mat + 1], m3 = materials[4 * mat + 3];
+        const int texture = (int)__float_as_uint(m1.w);
+        const uint32_t mode = __float_as_uint(m3.x);
+        if (texture < 0 && ((mode == 1u && m0.w < m3.y) || (mode == 2u && m0.w < 0.01f))) word = REF_INVISIBLE;
+    }
+    refs[3 * (size_t)r].w = __uint_as_float(word);
+}
+
 // One 48-byte record per reference, in cell order.
 __global__ void k_emit_refs(const uint32_t* __restrict__ indices, uint32_t n_refs, const float* __restrict__ tri_v,
                             uint32_t nb, uint32_t nt, float4* __restrict__ refs) {
@@ -325,6 +346,15 @@ int stage_in(rt_ctx* c, DevBuf& buf, const void* src, size_t bytes, const void**
 
 namespace rt {
 
+int apply_visibility(rt_ctx* c) {
+    if (!c->n_refs || !c->nt) return RT_OK;
+    hipLaunchKernelGGL(k_ref_visibility, dim3((c->n_refs + 255) / 256), dim3(256), 0, c->stream, c->indices.as<uint32_t>(),
+                       c->n_refs, c->grid_nb, c->nt, c->tri_mat.as<uint32_t>(), c->materials.as<float4>(), c->n_materials,
+                       c->refs.as<float4>());
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
 int emit_refs_from_csr(rt_ctx* c) {
     const uint32_t* g = c->meta.grid_sizes[RT_GRID_LEVELS - 1];
     const unsigned long long bordered = (g[0] + 2ull) * (g[1] + 2ull) * (g[2] + 2ull);
@@ -342,7 +372,7 @@ int emit_refs_from_csr(rt_ctx* c) {
                            c->refs.as<float4>());
         RT_HIP(c, hipGetLastError());
     }
-    return RT_OK;
+    return apply_visibility(c);
 }
 
 }  // namespace rt
@@ -796,8 +826,10 @@ extern "C" int rt_set_materials(rt_ctx* c, const MaterialData* materials, uint32
     if (int r = scene_barrier(c)) return r;
     RT_HIP(c, c->materials.reserve((size_t)n * sizeof(MaterialData) + 16));
     if (n) RT_HIP(c, hipMemcpyAsync(c->materials.p, materials, (size_t)n * sizeof(MaterialData), hipMemcpyHostToDevice, c->stream));
-    RT_HIP(c, hipStreamSynchronize(c->stream));
     c->n_materials = n;
+    if (c->has_grid)
+        if (int r = apply_visibility(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

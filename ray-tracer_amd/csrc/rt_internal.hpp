@@ -124,5 +124,7 @@ inline bool is_device_ptr(const void* p) {
 int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode);
 // implemented in rt_api.hip: (cell_start, indices) on device -> cells + refs records
 int emit_refs_from_csr(rt_ctx* c);
+// implemented in rt_api.hip: rewrites the id word of triangle references from the current materials
+int apply_visibility(rt_ctx* c);
 
 }  // namespace rt

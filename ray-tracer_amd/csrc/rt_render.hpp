@@ -3,8 +3,10 @@
 // highlight and the texture store of main (:655-720), box colours (:230-233) and the untextured part of the
 // triangle material (:280-303, :345-364).
 //
-// Not here yet: texture sampling, normal maps, emissive textures and the alpha MASK / BLEND rejection inside the
-// triangle test (:286-329). A material that names textures is shaded with its constant factors alone.
+// The alpha MASK / BLEND rejection inside the triangle test (:310-321) is applied to the reference records when
+// materials are set (k_ref_visibility in rt_api.hip), for materials without a base-colour texture.
+// Not here yet: texture sampling, normal maps, emissive textures. A material that names textures is shaded with its
+// constant factors alone and never discards a hit.
 //
 // Same numerics contract as the trace: the reference's f32 expression trees, no contraction, host-evaluated
 // transcendental constants. The 8-bit store is round-to-nearest-even of clamp(c, 0, 1) * 255 (NaN -> 0).

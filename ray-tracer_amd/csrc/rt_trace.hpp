@@ -22,6 +22,9 @@ namespace rt {
 
 constexpr uint32_t MISS = 0xFFFFFFFFu;
 constexpr uint32_t REF_INVALID = 0xFFFFFFFEu;  // reference to a triangle index >= num_triangles: skipped
+// Triangle whose material discards every hit (untextured alpha MASK below its cutoff, or BLEND below 0.01,
+// raytracer_unified.wgsl:310-321): tested by the shader, never accepted.
+constexpr uint32_t REF_INVISIBLE = 0xFFFFFFFDu;
 constexpr uint32_t CELL_SENTINEL = 0xFFFFFFFFu;  // count of a border cell: the ray has left the grid
 constexpr uint32_t BOX_CULLED_GRID = 1u;       // LOD cull outcome when met through a grid cell
 constexpr uint32_t BOX_CULLED_PREPASS = 2u;    // LOD cull outcome in the moving-box pre-pass
@@ -227,7 +230,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         } else {
             if (STATS && id != REF_INVALID) ctr.tri++;
             const float t = moller_trumbore_pk<WGSL>(rp, c0, c1, c2);
-            if (t > 0.0f && t < closest && id != REF_INVALID) {
+            if (t > 0.0f && t < closest && id < REF_INVISIBLE) {
                 closest = t;
                 best_id = id;
                 best_ref = r;

@@ -174,3 +174,47 @@ def test_frame_sharder_on_the_gpu_single_rank(core, ob, rt, car_xyz9):
         gs = outs[k][1].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
         assert np.array_equal(gp["id"], wp["id"]) and np.array_equal(gp["t"].view(np.uint32), wp["t"].view(np.uint32))
         assert np.array_equal(gs["id"], ws["id"]) and np.array_equal(gs["t"].view(np.uint32), ws["t"].view(np.uint32))
+
+
+def test_alpha_rules_hit_records_and_picture(core, ob, rt, car_xyz9):
+    """Untextured alpha MASK / BLEND materials (raytracer_unified.wgsl:310-321) remove triangles from every
+    ray's view; set before the grid, after it, and taken away again."""
+    from test_oracle_render import alpha_materials
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    tris["material_id"] = np.arange(len(tris)) % 6
+    mats = alpha_materials(ob)
+    scene = ob.Scene(None, tris, materials=mats)
+    plain = ob.Scene(None, tris)
+    w, h = 240, 135
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+
+    def hits_equal(sc, what):
+        p, s = core.trace_primary(cam, w, h)
+        op, os_, _ = ob.trace_primary(sc, ocam(ob, cam), w, h)
+        for got, want in ((p, op), (s, os_)):
+            assert np.array_equal(got["id"], want["id"]), what
+            assert np.array_equal(got["t"].view(np.uint32), want["t"].view(np.uint32)), what
+        return op
+
+    core.set_scene(None, tris)
+    core.set_materials(mats)           # before the grid exists
+    core.build_grid()
+    op = hits_equal(scene, "materials before grid")
+    assert not np.isin(op["id"][op["id"] != ob.MISS] % 6, (1, 3)).any()
+    check(core, ob, scene, cam, w, h, what="picture with alpha")
+    check(core, ob, scene, cam, w, h, shadows=True, max_bounces=2, what="picture with alpha, shadows")
+    core.set_materials(None)           # taken away: everything visible again, grid untouched
+    op0 = hits_equal(plain, "materials removed")
+    assert np.isin(op0["id"][op0["id"] != ob.MISS] % 6, (1, 3)).any()
+    core.set_materials(mats)           # after the grid exists
+    hits_equal(scene, "materials after grid")
+    cs, idx = core.read_grid_csr()     # caller-supplied grid takes the same rule
+    meta = core.grid_info()[0]
+    core.set_grid_csr(meta, cs, idx)
+    hits_equal(scene, "caller-supplied grid")
+    core.set_collect_stats(True)       # the counters still count the tests the shader makes
+    core.trace_primary(cam, w, h)
+    _, _, st = ob.trace_primary(scene, ocam(ob, cam), w, h)
+    assert core.stats() == st
+    core.set_collect_stats(False)
+    core.set_materials(None)

@@ -78,3 +78,41 @@ def test_bounces_debug_pixel_grid_overlay_and_shards(ob):
             y0, x0 = (tile // tx) * th, (tile % tx) * tw
             canvas[y0:y0 + th, x0:x0 + tw] = part[lt][: h - y0, : w - x0]
     assert np.array_equal(canvas.reshape(-1, 4), full)
+
+
+def alpha_materials(ob):
+    """0 opaque, 1 MASK below its cutoff (invisible), 2 MASK above it, 3 BLEND nearly transparent (invisible),
+    4 MASK below the cutoff but textured (cannot be judged without the texture: stays visible)."""
+    m = np.zeros(5, ob.MATERIAL_DTYPE)
+    m["texture_index"] = m["normal_texture_index"] = m["emissive_texture_index"] = -1
+    m["roughness"] = 1.0
+    m["base_color"] = [(0.8, 0.2, 0.2, 1.0), (0.2, 0.8, 0.2, 0.3), (0.2, 0.2, 0.8, 0.7), (0.8, 0.8, 0.2, 0.005), (0.5, 0.5, 0.5, 0.1)]
+    m["alpha_mode"] = [0, 1, 1, 2, 1]
+    m["alpha_cutoff"] = [0.5, 0.5, 0.5, 0.5, 0.5]
+    m["texture_index"][4] = 0
+    return m
+
+
+def test_alpha_rules_make_triangles_invisible(ob, car_xyz9):
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    tris["material_id"] = np.arange(len(tris)) % 6  # 5: no such material
+    mats = alpha_materials(ob)
+    scene = ob.Scene(None, tris, materials=mats)
+    plain = ob.Scene(None, tris)
+    w, h = 160, 90
+    cam = ob.camera_to_uniform((200, 200, 300), 3.35, -0.28, 0.0, float(h))
+    p, s, _ = ob.trace_primary(scene, cam, w, h)
+    p0, _, _ = ob.trace_primary(plain, cam, w, h)
+    hit = p["id"] != ob.MISS
+    assert not np.isin(p["id"][hit] % 6, (1, 3)).any() and np.isin(p0["id"][p0["id"] != ob.MISS] % 6, (1, 3)).any()
+    sh = s["id"] != ob.MISS
+    assert not np.isin(s["id"][sh] % 6, (1, 3)).any()
+    assert np.isin(p["id"][hit] % 6, (4,)).any()  # the textured one is still there
+    # traversal agrees with testing every triangle
+    o, d = ob.primary_rays(cam, w, h)
+    brute = ob.trace_rays_bruteforce(scene, o, d)
+    assert np.array_equal(brute["id"], p["id"]) and np.array_equal(brute["t"].view(np.uint32), p["t"].view(np.uint32))
+    # the picture sees through them too
+    img, _ = ob.render(scene, cam, w, h)
+    img0, _ = ob.render(plain, cam, w, h, materials=mats)
+    assert (img != img0).any()

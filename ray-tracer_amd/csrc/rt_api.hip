@@ -114,6 +114,31 @@ __global__ void k_box_frame(const BoxData* __restrict__ boxes, uint32_t nb, floa
     out[4 * (size_t)i + 3] = make_float4(half.x, half.y, half.z, 0.f);
 }
 
+// Linear-blend skinning, one lane per triangle corner: S = ((w0*M[j0] + w1*M[j1]) + w2*M[j2]) + w3*M[j3] element
+// by element, then the point transform ((S.x*p.x + S.y*p.y) + S.z*p.z) + S.w (columns of S; glam's
+// transform_point3 order). Matrices are column-major, one per joint. Writes the trace's vertex array directly,
+// so the binning pass that follows reads what this kernel wrote without a trip through the host.
+__global__ void k_skin(const float* __restrict__ pos, const ushort4* __restrict__ joints, const float4* __restrict__ weights,
+                       const uint32_t* __restrict__ tri_idx, uint32_t n_corners, const float4* __restrict__ mats,
+                       float* __restrict__ tri_v) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_corners) return;
+    const uint32_t v = tri_idx[k];
+    const V3 p = ld3(pos + 3 * (size_t)v);
+    const ushort4 j = joints[v];
+    const float4 w = weights[v];
+    V3 col[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 a = mats[4 * j.x + c], b = mats[4 * j.y + c], d = mats[4 * j.z + c], e = mats[4 * j.w + c];
+        col[c] = ((v3(a.x, a.y, a.z) * w.x + v3(b.x, b.y, b.z) * w.y) + v3(d.x, d.y, d.z) * w.z) + v3(e.x, e.y, e.z) * w.w;
+    }
+    const V3 out = ((col[0] * p.x + col[1] * p.y) + col[2] * p.z) + col[3];
+    tri_v[3 * (size_t)k] = out.x;
+    tri_v[3 * (size_t)k + 1] = out.y;
+    tri_v[3 * (size_t)k + 2] = out.z;
+}
+
 // Geometric normal per triangle: normalize(cross(v1 - v0, v2 - v0)) (src/core/triangle_intersection.rs:79).
 __global__ void k_tri_normals(const float* __restrict__ tri_v, uint32_t first, uint32_t count, float4* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,7 +477,8 @@ extern "C" void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->tri_n,     &c->tri_mat,   &c->materials,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
+    DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->tri_n,     &c->tri_mat,   &c->materials, &c->skin_pos, &c->skin_joints,
+                      &c->skin_weights, &c->skin_tri, &c->skin_mats,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
                       &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->b_obj_n, &c->b_obj_off, &c->b_obj_sum, &c->out_p,     &c->out_s,
                       &c->in_o,      &c->in_d,      &c->stats,      &c->misc};
@@ -537,6 +563,7 @@ extern "C" int rt_set_scene(rt_ctx* c, const BoxData* boxes, uint32_t nb, const 
     if ((uint64_t)nb + nt >= 0xFFFFFFF0ull) return fail(c, RT_ERR_LIMIT, "rt_set_scene: more than 2^32-16 objects");
     if (int r = scene_barrier(c)) return r;
     c->has_grid = false;
+    c->has_skin = false;  // a skin belongs to the triangles it was set for
     c->nb = nb;
     c->nt = nt;
     RT_HIP(c, c->boxes.reserve((size_t)nb * sizeof(BoxData) + 16));
@@ -816,6 +843,72 @@ extern "C" int rt_assemble_tiles_rgba8(rt_ctx* c, const uint8_t* gathered, uint3
                                        uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, uint8_t* image) {
     return assemble_tiles<uint32_t>(c, gathered, width, height, tile_w, tile_h, n_ranks, rank_stride, image,
                                     "rt_assemble_tiles_rgba8");
+}
+
+// ================================================================== skinning
+
+extern "C" int rt_set_skin(rt_ctx* c, const float* positions, const uint16_t* joints, const float* weights, uint32_t n_vertices,
+                           const uint32_t* tri_indices, uint32_t n_triangles) {
+    if (int r = use(c)) return r;
+    if (!positions || !joints || !weights || !tri_indices || !n_vertices)
+        return fail(c, RT_ERR_INVALID, "rt_set_skin: NULL or empty argument");
+    if (n_triangles != c->nt)
+        return fail(c, RT_ERR_INVALID, "rt_set_skin: %u triangles, the scene has %u (call rt_set_scene first)", n_triangles, c->nt);
+    for (size_t k = 0; k < (size_t)n_triangles * 3; ++k)
+        if (tri_indices[k] >= n_vertices) return fail(c, RT_ERR_INVALID, "rt_set_skin: vertex index %u of %u at %zu", tri_indices[k], n_vertices, k);
+    uint32_t max_joint = 0;
+    for (size_t k = 0; k < (size_t)n_vertices * 4; ++k) max_joint = std::max<uint32_t>(max_joint, joints[k]);
+    if (int r = scene_barrier(c)) return r;
+    RT_HIP(c, c->skin_pos.reserve((size_t)n_vertices * 12));
+    RT_HIP(c, c->skin_joints.reserve((size_t)n_vertices * 8));
+    RT_HIP(c, c->skin_weights.reserve((size_t)n_vertices * 16));
+    RT_HIP(c, c->skin_tri.reserve((size_t)n_triangles * 12 + 16));
+    RT_HIP(c, hipMemcpyAsync(c->skin_pos.p, positions, (size_t)n_vertices * 12, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(c->skin_joints.p, joints, (size_t)n_vertices * 8, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(c->skin_weights.p, weights, (size_t)n_vertices * 16, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(c->skin_tri.p, tri_indices, (size_t)n_triangles * 12, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->skin_nv = n_vertices;
+    c->skin_max_joint = max_joint;
+    c->has_skin = true;
+    return RT_OK;
+}
+
+extern "C" int rt_skin_vertices(rt_ctx* c, const float* joint_matrices, uint32_t n_joints) {
+    if (int r = use(c)) return r;
+    if (!c->has_skin) return fail(c, RT_ERR_STATE, "rt_skin_vertices: no skin (call rt_set_skin)");
+    if (!joint_matrices) return fail(c, RT_ERR_INVALID, "rt_skin_vertices: NULL matrices");
+    if (n_joints <= c->skin_max_joint)
+        return fail(c, RT_ERR_INVALID, "rt_skin_vertices: %u matrices, the skin uses joint %u", n_joints, c->skin_max_joint);
+    if (!c->nt) return RT_OK;
+    if (int r = scene_barrier(c)) return r;
+    const float4* mats = reinterpret_cast<const float4*>(joint_matrices);
+    const bool dev = is_device_ptr(joint_matrices);
+    if (!dev) {
+        RT_HIP(c, c->skin_mats.reserve((size_t)n_joints * 64));
+        RT_HIP(c, hipMemcpyAsync(c->skin_mats.p, joint_matrices, (size_t)n_joints * 64, hipMemcpyHostToDevice, c->stream));
+        mats = c->skin_mats.as<float4>();
+    }
+    const uint32_t corners = c->nt * 3;
+    hipLaunchKernelGGL(k_skin, dim3((corners + 255) / 256), dim3(256), 0, c->stream, c->skin_pos.as<float>(),
+                       c->skin_joints.as<ushort4>(), c->skin_weights.as<float4>(), c->skin_tri.as<uint32_t>(), corners, mats,
+                       c->tri_v.as<float>());
+    hipLaunchKernelGGL(k_tri_normals, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->tri_v.as<float>(), 0u, c->nt,
+                       c->tri_n.as<float4>());
+    RT_HIP(c, hipGetLastError());
+    if (!dev) RT_HIP(c, hipStreamSynchronize(c->stream));  // the caller may reuse its matrix array
+    c->has_grid = false;  // cell lists and reference records are stale now
+    return RT_OK;
+}
+
+extern "C" int rt_read_vertices(rt_ctx* c, float* xyz9) {
+    if (int r = use(c)) return r;
+    if (!xyz9) return fail(c, RT_ERR_INVALID, "rt_read_vertices: NULL output");
+    if (c->nt) {
+        RT_HIP(c, hipMemcpyAsync(xyz9, c->tri_v.p, (size_t)c->nt * 36, hipMemcpyDefault, c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return RT_OK;
 }
 
 // ================================================================== shaded picture

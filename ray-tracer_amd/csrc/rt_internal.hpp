@@ -63,6 +63,10 @@ struct rt_ctx {
     rt::DevBuf tri_mat;    // u32[nt]: u32(TriangleData::material_id)
     rt::DevBuf materials;  // MaterialData[n_materials]
     uint32_t n_materials = 0;
+    // skin (rt_set_skin): per-vertex bind position, joint indices, weights; per-triangle vertex indices
+    rt::DevBuf skin_pos, skin_joints, skin_weights, skin_tri, skin_mats;
+    uint32_t skin_nv = 0, skin_max_joint = 0;
+    bool has_skin = false;
 
     // grid
     bool has_grid = false;

@@ -199,6 +199,28 @@ class TraceCore:
         self._ck(self._L.rt_update_vertices(self._h, _ptr(xyz9), first, n if count is None else count))
 
     # ---- tracing
+    # ---- skinning
+    def set_skin(self, positions, joints, weights, tri_indices):
+        positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        joints = np.ascontiguousarray(joints, np.uint16).reshape(-1, 4)
+        weights = np.ascontiguousarray(weights, np.float32).reshape(-1, 4)
+        tri_indices = np.ascontiguousarray(tri_indices, np.uint32).reshape(-1, 3)
+        if not (len(positions) == len(joints) == len(weights)):
+            raise ValueError("positions, joints and weights must describe the same vertices")
+        self._ck(self._L.rt_set_skin(self._h, _ptr(positions), _ptr(joints), _ptr(weights), len(positions),
+                                     _ptr(tri_indices), len(tri_indices)))
+
+    def skin_vertices(self, joint_matrices):
+        """(n_joints, 16) float32 column-major matrices: numpy array or a torch CUDA tensor."""
+        if isinstance(joint_matrices, np.ndarray):
+            joint_matrices = np.ascontiguousarray(joint_matrices, np.float32).reshape(-1, 16)
+        self._ck(self._L.rt_skin_vertices(self._h, _ptr(joint_matrices), joint_matrices.shape[0]))
+
+    def read_vertices(self):
+        out = np.empty((self.nt, 9), np.float32)
+        self._ck(self._L.rt_read_vertices(self._h, _ptr(out)))
+        return out
+
     def trace_primary(self, cam, width, height, shard=None, shadow=True, out_primary=None, out_shadow=None):
         """Returns (primary, shadow|None). Pass torch CUDA tensors (n,2 int32/8 bytes per record) or
         device pointers as out_* to keep results on the GPU; default is new numpy HIT_DTYPE arrays."""

@@ -175,6 +175,45 @@ def animated_pipelined(n_ctx=2):
         c.close()
 
 
+def animated_skinned(n_ctx=2):
+    """The bundled animated model with its own skeleton animation: per frame 89 joint matrices go to the GPU
+    (5.7 KB), the skinning kernel writes the vertex array, the binning pass reads it, the frame is traced."""
+    from ray_tracer_amd.animation import SkinnedModel
+    w, h = 1920, 1080
+    model = SkinnedModel(os.path.join(ROOT, "tests", "golden", "phoenix_skin.npz"))
+    mats = [model.joint_matrices(model.duration * f / 120) for f in range(120)]
+    cores = []
+    for _ in range(n_ctx):
+        c = rt.TraceCore(0)
+        c.set_scene(None, rt.triangles_from_xyz9(model.bind_pose_triangles()))
+        c.set_skin(model.positions, model.joints, model.weights, model.tri_indices)
+        cores.append(c)
+    outs = [(torch.empty((w * h, 2), dtype=torch.int32, device="cuda"), torch.empty((w * h, 2), dtype=torch.int32, device="cuda"))
+            for _ in range(n_ctx)]
+    cam = rt.Camera((-300, 250, 600), 2.7, -0.2).to_uniform(0.0, float(h))
+    hits = []
+
+    def run(count):
+        for f, jm in enumerate(mats):
+            c, (p, s) = cores[f % n_ctx], outs[f % n_ctx]
+            c.skin_vertices(jm)
+            c.build_grid()
+            c.trace_primary(cam, w, h, out_primary=p, out_shadow=s)
+            if count and f % 30 == 0:
+                hits.append(w * h + int((p[:, 0] != -1).sum()))
+        torch.cuda.synchronize()
+
+    run(True)
+    t0 = time.perf_counter()
+    run(False)
+    ms = (time.perf_counter() - t0) * 1e3 / len(mats)
+    emit(config="animated model, skeleton animation skinned on the GPU, 1920x1080 primary+shadow, per-frame rebuild",
+         contexts=n_ctx, triangles=len(model.tri_indices), joints=len(mats[0]), frames=len(mats), frame_ms=ms,
+         rays_sampled=hits, Mrays_per_s_with_skinning_and_rebuild=float(np.mean(hits)) / ms / 1e3)
+    for c in cores:
+        c.close()
+
+
 if __name__ == "__main__":
     what = set(sys.argv[1:]) or {"micro", "massive", "animated", "rays"}
     big = "big" in what
@@ -186,7 +225,8 @@ if __name__ == "__main__":
     if "animated" in what:
         animated(core)
         animated_pipelined(2)
-        animated_pipelined(3)
+        animated_skinned(1)
+        animated_skinned(2)
     if "rays" in what:
         rays(core, (100000, 1000000))
     if "massive" in what:

@@ -192,6 +192,23 @@ int rt_assemble_tiles(rt_ctx* ctx, const rt_hit* gathered, uint32_t width, uint3
 int rt_debug_pixel(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
                    uint32_t px, uint32_t py, RayDebugInfo* info);
 
+/* ---- bounding volume hierarchy ----------------------------------------------------------- */
+
+/* BVHStats (src/core/bvh.rs:34-40). */
+typedef struct rt_bvh_stats {
+    uint64_t node_count, leaf_count, max_depth, total_primitives;
+} rt_bvh_stats;
+
+/* BVHNode::build over the scene's triangles (src/core/bvh.rs:44-232: binned SAH, 12 buckets, leaves of up
+ * to 4), built on the host from the current vertices and uploaded; rebuilt by the caller after rt_set_scene,
+ * rt_update_vertices or rt_skin_vertices. */
+int rt_build_bvh(rt_ctx* ctx);
+int rt_get_bvh_stats(rt_ctx* ctx, rt_bvh_stats* stats);
+/* traverse_bvh_triangles of the reference's benchmark (examples/massive_benchmark.rs:226-270,311-320) for a list
+ * of rays: both children of every node whose box the ray meets, Moller-Trumbore in the leaves, smallest t.
+ * out_t[i] = t, or -1 when nothing is hit (the example's None). origins/dirs/out_t all host or all device. */
+int rt_trace_rays_bvh(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n, float* out_t);
+
 /* ---- skinning (animated models) --------------------------------------------------------- */
 
 /* The reference loads animated models in their bind pose only (src/loaders/gltf_triangles.rs:179-283 walks

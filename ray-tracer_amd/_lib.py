@@ -69,6 +69,11 @@ class RtStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class RtBvhStats(C.Structure):
+    _fields_ = [("node_count", C.c_uint64), ("leaf_count", C.c_uint64), ("max_depth", C.c_uint64),
+                ("total_primitives", C.c_uint64)]
+
+
 class RtRenderOpts(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("shadows", C.c_uint32), ("debug_enabled", C.c_uint32),
                 ("debug_pixel", C.c_uint32 * 2), ("_pad", C.c_uint32 * 3)]
@@ -104,6 +109,9 @@ PROTOTYPES = {
     "rt_trace_primary": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), _VP, _VP]),
     "rt_trace_rays": (_I, [_VP, C.POINTER(CameraUniform), _VP, _VP, _U32, _VP, _I]),
     "rt_assemble_tiles": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
+    "rt_build_bvh": (_I, [_VP]),
+    "rt_get_bvh_stats": (_I, [_VP, C.POINTER(RtBvhStats)]),
+    "rt_trace_rays_bvh": (_I, [_VP, _VP, _VP, _U32, _VP]),
     "rt_set_skin": (_I, [_VP, _VP, _VP, _VP, _U32, _VP, _U32]),
     "rt_skin_vertices": (_I, [_VP, _VP, _U32]),
     "rt_read_vertices": (_I, [_VP, _VP]),

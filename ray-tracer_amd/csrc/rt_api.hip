@@ -478,7 +478,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->tri_n,     &c->tri_mat,   &c->materials, &c->skin_pos, &c->skin_joints,
-                      &c->skin_weights, &c->skin_tri, &c->skin_mats,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
+                      &c->skin_weights, &c->skin_tri, &c->skin_mats, &c->bvh_nodes, &c->bvh_leaf_first, &c->bvh_prims, &c->bvh_recs,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
                       &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->b_obj_n, &c->b_obj_off, &c->b_obj_sum, &c->out_p,     &c->out_s,
                       &c->in_o,      &c->in_d,      &c->stats,      &c->misc};
@@ -564,6 +564,7 @@ extern "C" int rt_set_scene(rt_ctx* c, const BoxData* boxes, uint32_t nb, const 
     if (int r = scene_barrier(c)) return r;
     c->has_grid = false;
     c->has_skin = false;  // a skin belongs to the triangles it was set for
+    c->has_bvh = false;
     c->nb = nb;
     c->nt = nt;
     RT_HIP(c, c->boxes.reserve((size_t)nb * sizeof(BoxData) + 16));
@@ -707,6 +708,7 @@ extern "C" int rt_update_vertices(rt_ctx* c, const float* xyz9, uint32_t first, 
     RT_HIP(c, hipGetLastError());
     if (!dev) RT_HIP(c, hipStreamSynchronize(c->stream));
     c->has_grid = false;  // cell lists and reference records are stale now
+    c->has_bvh = false;
     return RT_OK;
 }
 
@@ -898,6 +900,7 @@ extern "C" int rt_skin_vertices(rt_ctx* c, const float* joint_matrices, uint32_t
     RT_HIP(c, hipGetLastError());
     if (!dev) RT_HIP(c, hipStreamSynchronize(c->stream));  // the caller may reuse its matrix array
     c->has_grid = false;  // cell lists and reference records are stale now
+    c->has_bvh = false;
     return RT_OK;
 }
 

@@ -15,7 +15,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import (BOX_DTYPE, HIT_DTYPE, MATERIAL_DTYPE, RtRenderOpts, RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES, RT_MISS, TRIANGLE_DTYPE,
+from ._lib import (BOX_DTYPE, HIT_DTYPE, MATERIAL_DTYPE, RtBvhStats, RtRenderOpts, RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES, RT_MISS, TRIANGLE_DTYPE,
                    CameraUniform, GridMetadata, RayDebugInfo, RtParams, RtShard, RtStats)
 
 DEFAULT_FOV = 0.785398  # raytracer_unified.wgsl:4, src/renderer.rs DEFAULT_FOV
@@ -199,6 +199,26 @@ class TraceCore:
         self._ck(self._L.rt_update_vertices(self._h, _ptr(xyz9), first, n if count is None else count))
 
     # ---- tracing
+    # ---- bounding volume hierarchy
+    def build_bvh(self):
+        """Returns BVHStats as a dict."""
+        self._ck(self._L.rt_build_bvh(self._h))
+        st = RtBvhStats()
+        self._ck(self._L.rt_get_bvh_stats(self._h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in st._fields_}
+
+    def trace_rays_bvh(self, origins, dirs, out=None, n=None):
+        """Closest t per ray (-1 = none). numpy in -> numpy out; torch CUDA tensors throughout with `out`."""
+        if out is None:
+            origins = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+            dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+            out = np.empty(len(origins), np.float32)
+            n = len(origins)
+        elif n is None:
+            n = origins.shape[0]
+        self._ck(self._L.rt_trace_rays_bvh(self._h, _ptr(origins), _ptr(dirs), n, _ptr(out)))
+        return out
+
     # ---- skinning
     def set_skin(self, positions, joints, weights, tri_indices):
         positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)

@@ -69,3 +69,18 @@ def rotate_about_y(xyz9, frame, frames_per_turn=120):
     out[:, 1] = p[:, 1] + c[1] + f32(10.0 * (np.sin(2.0 * frame / 60.0) + 1.0) / 2.0)
     out[:, 2] = -sa * p[:, 0] + ca * p[:, 2] + c[2]
     return out.reshape(-1, 9)
+
+
+def primary_rays(camera_uniform, width, height, fov=0.785398):
+    """The shader's ray generation (raytracer_unified.wgsl:625-653) in numpy float32, for feeding ray-list entry
+    points with a frame's primary rays. Returns (origins, dirs), each (width*height, 3)."""
+    px, py = np.meshgrid(np.arange(width, dtype=f32), np.arange(height, dtype=f32))
+    u = (px.reshape(-1) + f32(0.5)) / f32(width)
+    v = (py.reshape(-1) + f32(0.5)) / f32(height)
+    ndc_x, ndc_y = u * f32(2.0) - f32(1.0), v * f32(2.0) - f32(1.0)
+    aspect, scale = f32(width) / f32(height), f32(np.tan(f32(fov)))
+    fwd, right, up = (np.array(list(getattr(camera_uniform, k)), f32) for k in ("forward", "right", "up"))
+    d = fwd[None, :] + right[None, :] * (ndc_x * aspect * scale)[:, None] + up[None, :] * (-ndc_y * scale)[:, None]
+    d = (d / np.sqrt((d * d).sum(axis=1, dtype=f32))[:, None]).astype(f32)
+    o = np.tile(np.array(list(camera_uniform.position), f32), (width * height, 1))
+    return o, d

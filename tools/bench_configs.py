@@ -175,6 +175,33 @@ def animated_pipelined(n_ctx=2):
         c.close()
 
 
+def bvh(core):
+    """The structure the reference's own benchmark times (BVH build + both-children traversal), on the GPU, beside
+    the grid walk on the same rays."""
+    cases = []
+    car = np.load(os.path.join(ROOT, "tests", "golden", "car_tris.npy"))
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, 1080.0)
+    cases.append(("bundled static model, the 1920x1080 frame's primary rays", rt.triangles_from_xyz9(car),
+                  wl.primary_rays(cam, 1920, 1080), 16.0))
+    for n in (100000, 1000000):
+        cases.append((f"massive_benchmark scene, {n} triangles, 2,000,000 generate_test_rays", wl.generate_test_triangles(n),
+                      wl.generate_test_rays(2000000), 2.0))
+    for label, tris, (o, d), cell in cases:
+        core.set_scene(None, tris)
+        t0 = time.perf_counter()
+        st = core.build_bvh()
+        build_ms = (time.perf_counter() - t0) * 1e3
+        to, td = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+        out = torch.empty(len(o), dtype=torch.float32, device="cuda")
+        ms = timed(core, lambda: core.trace_rays_bvh(to, td, out=out), 5)
+        core.build_grid(cell_size=cell)
+        hits = torch.empty((len(o), 2), dtype=torch.int32, device="cuda")
+        gms = timed(core, lambda: core.trace_rays(to, td, out=hits, n=len(o)), 5)
+        emit(config="BVH path: " + label, triangles=len(tris), rays=len(o), bvh_nodes=st["node_count"], bvh_depth=st["max_depth"],
+             bvh_build_ms_host=build_ms, bvh_trace_ms=ms, bvh_Mrays_per_s=len(o) / ms / 1e3, bvh_hits=int((out >= 0).sum()),
+             grid_cell=cell, grid_trace_ms=gms, grid_Mrays_per_s=len(o) / gms / 1e3, grid_hits=int((hits[:, 0] != -1).sum()))
+
+
 def animated_skinned(n_ctx=2):
     """The bundled animated model with its own skeleton animation: per frame 89 joint matrices go to the GPU
     (5.7 KB), the skinning kernel writes the vertex array, the binning pass reads it, the frame is traced."""
@@ -215,7 +242,7 @@ def animated_skinned(n_ctx=2):
 
 
 if __name__ == "__main__":
-    what = set(sys.argv[1:]) or {"micro", "massive", "animated", "rays"}
+    what = set(sys.argv[1:]) or {"micro", "massive", "animated", "rays", "bvh"}
     big = "big" in what
     core = rt.TraceCore(0)
     P = torch.empty((3840 * 2160, 2), dtype=torch.int32, device="cuda")
@@ -227,6 +254,8 @@ if __name__ == "__main__":
         animated_pipelined(2)
         animated_skinned(1)
         animated_skinned(2)
+    if "bvh" in what:
+        bvh(core)
     if "rays" in what:
         rays(core, (100000, 1000000))
     if "massive" in what:

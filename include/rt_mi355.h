@@ -279,6 +279,9 @@ int rt_intersect_aabb_pairs(rt_ctx* ctx, const float* origins, const float* dirs
                             const float* box_min, const float* box_max, uint32_t n_prims, float* out_t);
 int rt_intersect_tri_pairs(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n_rays,
                            const float* v012, uint32_t n_prims, float* out_t);
+/* Same, with watertight_intersect (src/core/triangle_intersection.rs:101-181) as the triangle test. */
+int rt_intersect_tri_pairs_watertight(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n_rays,
+                                      const float* v012, uint32_t n_prims, float* out_t);
 
 /* ---- timing --------------------------------------------------------------------------- */
 

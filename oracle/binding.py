@@ -156,6 +156,8 @@ def lib():
         L.orc_trace_primary.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32,
                                         C.c_uint32, C.POINTER(Shard), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(Stats), C.c_int]
+        L.orc_watertight_pairs.restype = None
+        L.orc_watertight_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_skin_vertices.restype = None
         L.orc_skin_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_render.restype = None
@@ -276,6 +278,13 @@ def intersect_aabb_pairs(origins, dirs, box_min, box_max, wgsl_compat=0):
     out = np.empty((len(origins), len(box_min)), f32)
     lib().orc_intersect_aabb_pairs(_ptr(origins), _ptr(dirs), len(origins), _ptr(box_min), _ptr(box_max),
                                    len(box_min), wgsl_compat, _ptr(out))
+    return out
+
+
+def watertight_pairs(origins, dirs, v012):
+    origins, dirs, v012 = _c(origins, f32).reshape(-1, 3), _c(dirs, f32).reshape(-1, 3), _c(v012, f32).reshape(-1, 9)
+    out = np.empty((len(origins), len(v012)), f32)
+    lib().orc_watertight_pairs(_ptr(origins), _ptr(dirs), len(origins), _ptr(v012), len(v012), _ptr(out))
     return out
 
 

@@ -265,6 +265,16 @@ extern "C" void orc_intersect_aabb_pairs(const float* origins, const float* dirs
                                                             ld(box_max + 3 * p), wgsl_compat);
 }
 
+extern "C" void orc_watertight_pairs(const float* origins, const float* dirs, uint32_t n_rays, const float* v012,
+                                     uint32_t n_prims, float* out_t) {
+    for (uint32_t r = 0; r < n_rays; ++r)
+        for (uint32_t p = 0; p < n_prims; ++p) {
+            const float* v = v012 + 9 * (size_t)p;
+            TriHit h;
+            out_t[(size_t)r * n_prims + p] = watertight(ld(origins + 3 * r), ld(dirs + 3 * r), ld(v), ld(v + 3), ld(v + 6), &h) ? h.t : -1.0f;
+        }
+}
+
 extern "C" void orc_intersect_tri_pairs(const float* origins, const float* dirs, uint32_t n_rays, const float* v012,
                                         uint32_t n_prims, int wgsl_compat, float* out_t) {
     for (uint32_t r = 0; r < n_rays; ++r)

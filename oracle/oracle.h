@@ -56,6 +56,9 @@ void orc_triangle_bounds(const TriangleData* t, float omin[3], float omax[3]);
 /* all-pairs forms (shape of the criterion loops) */
 void orc_intersect_aabb_pairs(const float* origins, const float* dirs, uint32_t n_rays, const float* box_min,
                               const float* box_max, uint32_t n_prims, int wgsl_compat, float* out_t);
+/* watertight_intersect (src/core/triangle_intersection.rs:101-181) for every (ray, triangle) pair: t or -1. */
+void orc_watertight_pairs(const float* origins, const float* dirs, uint32_t n_rays, const float* v012, uint32_t n_prims,
+                          float* out_t);
 void orc_intersect_tri_pairs(const float* origins, const float* dirs, uint32_t n_rays, const float* v012,
                              uint32_t n_prims, int wgsl_compat, float* out_t);
 

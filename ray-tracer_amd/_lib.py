@@ -124,6 +124,7 @@ PROTOTYPES = {
     "rt_set_collect_stats": (_I, [_VP, _I]),
     "rt_intersect_aabb_pairs": (_I, [_VP, _VP, _VP, _U32, _VP, _VP, _U32, _VP]),
     "rt_intersect_tri_pairs": (_I, [_VP, _VP, _VP, _U32, _VP, _U32, _VP]),
+    "rt_intersect_tri_pairs_watertight": (_I, [_VP, _VP, _VP, _U32, _VP, _U32, _VP]),
     "rt_timer_begin": (_I, [_VP]),
     "rt_timer_end": (_I, [_VP, C.POINTER(C.c_float)]),
 }

@@ -186,6 +186,15 @@ __global__ void k_tri_pairs(const float* __restrict__ o, const float* __restrict
                                       make_float4(e1.x, e1.y, e1.z, 0.f), make_float4(e2.x, e2.y, e2.z, 0.f));
 }
 
+__global__ void k_tri_pairs_watertight(const float* __restrict__ o, const float* __restrict__ d, uint32_t n_rays,
+                                       const float* __restrict__ v012, uint32_t n_prims, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_rays * n_prims) return;
+    uint32_t r = (uint32_t)(i / n_prims), p = (uint32_t)(i % n_prims);
+    const float* v = v012 + 9 * (size_t)p;
+    out[i] = watertight(ld3(o + 3 * (size_t)r), ld3(d + 3 * (size_t)r), ld3(v), ld3(v + 3), ld3(v + 6));
+}
+
 template <class PIXEL>
 __global__ void k_assemble(const PIXEL* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w,
                            uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks, size_t per_rank,
@@ -1050,8 +1059,8 @@ extern "C" int rt_intersect_aabb_pairs(rt_ctx* c, const float* origins, const fl
     return RT_OK;
 }
 
-extern "C" int rt_intersect_tri_pairs(rt_ctx* c, const float* origins, const float* dirs, uint32_t n_rays,
-                                      const float* v012, uint32_t n_prims, float* out_t) {
+static int tri_pairs(rt_ctx* c, const float* origins, const float* dirs, uint32_t n_rays, const float* v012,
+                     uint32_t n_prims, float* out_t, bool use_watertight) {
     if (int r = use(c)) return r;
     const size_t n = (size_t)n_rays * n_prims;
     if (n == 0) return RT_OK;
@@ -1072,7 +1081,9 @@ extern "C" int rt_intersect_tri_pairs(rt_ctx* c, const float* origins, const flo
         RT_HIP(c, hipMemcpyAsync((void*)d_v, v012, pb, hipMemcpyHostToDevice, c->stream));
     }
     const dim3 grid((uint32_t)((n + 255) / 256));
-    if (c->params.wgsl_compat)
+    if (use_watertight)
+        hipLaunchKernelGGL(k_tri_pairs_watertight, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_v, n_prims, d_out);
+    else if (c->params.wgsl_compat)
         hipLaunchKernelGGL(k_tri_pairs<true>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_v, n_prims, d_out);
     else
         hipLaunchKernelGGL(k_tri_pairs<false>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_v, n_prims, d_out);
@@ -1082,6 +1093,16 @@ extern "C" int rt_intersect_tri_pairs(rt_ctx* c, const float* origins, const flo
         RT_HIP(c, hipStreamSynchronize(c->stream));
     }
     return RT_OK;
+}
+
+extern "C" int rt_intersect_tri_pairs(rt_ctx* c, const float* origins, const float* dirs, uint32_t n_rays,
+                                      const float* v012, uint32_t n_prims, float* out_t) {
+    return tri_pairs(c, origins, dirs, n_rays, v012, n_prims, out_t, false);
+}
+
+extern "C" int rt_intersect_tri_pairs_watertight(rt_ctx* c, const float* origins, const float* dirs, uint32_t n_rays,
+                                                 const float* v012, uint32_t n_prims, float* out_t) {
+    return tri_pairs(c, origins, dirs, n_rays, v012, n_prims, out_t, true);
 }
 
 #ifdef RT_EXPERIMENTS

@@ -112,6 +112,33 @@ __host__ __device__ inline float moller_trumbore(V3 o, V3 d, V3 v0, V3 e1, V3 e2
     return t;
 }
 
+// The reference's second triangle routine, the "watertight" test (src/core/triangle_intersection.rs:101-181):
+// shear the triangle into the ray's frame along its dominant axis, take the three signed edge functions, accept
+// when they do not disagree in sign. Returns t, or -1.
+__host__ __device__ inline float watertight(V3 o, V3 d, V3 v0, V3 v1, V3 v2) {
+    const float eps = 1e-6f;
+    const V3 a = v0 - o, b = v1 - o, c = v2 - o;
+    const V3 ad = vabs(d);
+    const int kz = (ad.x > ad.y && ad.x > ad.z) ? 0 : (ad.y > ad.z ? 1 : 2);
+    const int kx = (kz + 1) % 3, ky = (kx + 1) % 3;
+    auto at = [](V3 p, int k) { return k == 0 ? p.x : (k == 1 ? p.y : p.z); };
+    const float dx = at(d, kx), dy = at(d, ky), dz = at(d, kz);
+    const float sx = dx / dz, sy = dy / dz, sz = 1.0f / dz;
+    const float ax = at(a, kx) - sx * at(a, kz), ay = at(a, ky) - sy * at(a, kz);
+    const float bx = at(b, kx) - sx * at(b, kz), by = at(b, ky) - sy * at(b, kz);
+    const float cx = at(c, kx) - sx * at(c, kz), cy = at(c, ky) - sy * at(c, kz);
+    const float u = cx * by - cy * bx;
+    const float v = ax * cy - ay * cx;
+    const float w = bx * ay - by * ax;
+    if ((u < 0.0f || v < 0.0f || w < 0.0f) && (u > 0.0f || v > 0.0f || w > 0.0f)) return -1.0f;
+    const float det = u + v + w;
+    if (fabsf(det) < eps) return -1.0f;
+    const float az = sz * at(a, kz), bz = sz * at(b, kz), cz = sz * at(c, kz);
+    const float t = (u * az + v * bz + w * cz) * (1.0f / det);
+    if (t < eps) return -1.0f;
+    return t;
+}
+
 #if defined(__HIPCC__)
 // The same test written for the packed two-lane f32 instructions of gfx950 (v_pk_mul_f32, v_pk_add_f32), which run
 // at the rate of the one-lane forms. Every product and sum below is one of the reference's, with the same operands

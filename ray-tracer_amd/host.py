@@ -322,16 +322,16 @@ class TraceCore:
                                                  _ptr(box_max), len(box_min), _ptr(out)))
         return out
 
-    def intersect_tri_pairs(self, origins, dirs, v012, out=None):
+    def intersect_tri_pairs(self, origins, dirs, v012, out=None, watertight=False):
+        fn = self._L.rt_intersect_tri_pairs_watertight if watertight else self._L.rt_intersect_tri_pairs
         if out is not None:  # device tensors throughout
-            self._ck(self._L.rt_intersect_tri_pairs(self._h, _ptr(origins), _ptr(dirs), origins.shape[0], _ptr(v012),
+            self._ck(fn(self._h, _ptr(origins), _ptr(dirs), origins.shape[0], _ptr(v012),
                                                     v012.shape[0], _ptr(out)))
             return out
         origins, dirs = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (origins, dirs))
         v012 = np.ascontiguousarray(v012, np.float32).reshape(-1, 9)
         out = np.empty((len(origins), len(v012)), np.float32)
-        self._ck(self._L.rt_intersect_tri_pairs(self._h, _ptr(origins), _ptr(dirs), len(origins), _ptr(v012), len(v012),
-                                                _ptr(out)))
+        self._ck(fn(self._h, _ptr(origins), _ptr(dirs), len(origins), _ptr(v012), len(v012), _ptr(out)))
         return out
 
 

@@ -108,6 +108,24 @@ def test_tri_pairs(rt, ob, car_xyz9, wgsl):
     core.close()
 
 
+def test_watertight_pairs(core, ob, car_xyz9):
+    """watertight_intersect (src/core/triangle_intersection.rs:101-181) on the GPU: bit-identical to the oracle's
+    restatement, close to Moller-Trumbore (the reference's own test asks for |dt| < 0.1, :286-301), and the
+    reference's known answer t = 5."""
+    o, d = special_rays()
+    cam = ob.camera_to_uniform((200, 200, 300), 3.35, -0.28, 0.0, 16.0)
+    po, pd = ob.primary_rays(cam, 24, 16)
+    o, d = np.concatenate([o, po]), np.concatenate([d, pd])
+    got, want = core.intersect_tri_pairs(o, d, car_xyz9, watertight=True), ob.watertight_pairs(o, d, car_xyz9)
+    assert np.array_equal(bits(got), bits(want)) and (want > 0).sum() > 100
+    mt = core.intersect_tri_pairs(o, d, car_xyz9)
+    both = (got > 0) & (mt > 0)
+    assert both.sum() > 100 and np.abs(got[both] - mt[both]).max() < 0.1
+    tri = np.array([[-1, 0, -5, 1, 0, -5, 0, 1, -5]], np.float32)
+    t = core.intersect_tri_pairs(np.zeros((1, 3), np.float32), np.array([[0, 0.1, -1]], np.float32) / np.float32(np.hypot(0.1, 1)), tri, watertight=True)
+    assert abs(float(t[0, 0]) - 5.0 * np.hypot(0.1, 1)) < 1e-4
+
+
 def test_reference_known_answers_on_gpu(core):
     """src/math/ray.rs:43-71 and src/core/triangle_intersection.rs:219-252,357-364 evaluated by the kernels."""
     t = core.intersect_aabb_pairs([(0, 0, 0), (0, 0, 0), (5, 0, 0)], [(1, 0, 0)] * 3,

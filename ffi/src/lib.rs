@@ -41,6 +41,14 @@ extern "C" {
                          out: *mut RtHit, any_hit: c_int) -> c_int;
     pub fn rt_set_stream(ctx: *mut RtCtx, hip_stream: *mut c_void) -> c_int;
     pub fn rt_set_materials(ctx: *mut RtCtx, materials: *const c_void, n: u32) -> c_int;
+    pub fn rt_set_skin(ctx: *mut RtCtx, positions: *const f32, joints: *const u16, weights: *const f32, n_vertices: u32,
+                       tri_indices: *const u32, n_triangles: u32) -> c_int;
+    pub fn rt_skin_vertices(ctx: *mut RtCtx, joint_matrices: *const f32, n_joints: u32) -> c_int;
+    pub fn rt_read_vertices(ctx: *mut RtCtx, xyz9: *mut f32) -> c_int;
+    pub fn rt_build_bvh(ctx: *mut RtCtx) -> c_int;
+    pub fn rt_trace_rays_bvh(ctx: *mut RtCtx, origins: *const f32, dirs: *const f32, n: u32, out_t: *mut f32) -> c_int;
+    pub fn rt_intersect_tri_pairs_watertight(ctx: *mut RtCtx, origins: *const f32, dirs: *const f32, n_rays: u32,
+                                             v012: *const f32, n_prims: u32, out_t: *mut f32) -> c_int;
     pub fn rt_default_render_opts(o: *mut RtRenderOpts);
     pub fn rt_render(ctx: *mut RtCtx, camera: *const c_void, width: u32, height: u32, shard: *const RtShard,
                      opts: *const RtRenderOpts, out_rgba8: *mut u8) -> c_int;

@@ -241,13 +241,29 @@ void rt_default_render_opts(rt_render_opts* o);
 
 /* Replaces the "Materials" storage buffer (src/renderer.rs:147-156): MaterialData records
  * indexed by TriangleData::material_id. Without it every triangle is the shader's grey
- * (wgsl:366-370). Evaluated: base colour, emissive, metallic (= reflectivity), and the alpha
- * rules of the triangle test for materials without a base-colour texture (MASK below
- * alpha_cutoff / BLEND below 0.01 discard every hit, wgsl:310-321) - those triangles become
- * invisible to rt_trace_primary, rt_trace_rays and rt_render alike, whether the materials
- * arrive before or after the grid. Not evaluated yet: texture sampling (a textured material
- * keeps its triangles visible and is shaded with its constant factors), normal maps. */
+ * (wgsl:366-370). Evaluated as the shader's triangle test does (wgsl:279-366): base colour
+ * (factor times the base-colour texture when texture_index >= 0), the alpha rules (MASK below
+ * alpha_cutoff / BLEND below 0.01 discard the hit, so the ray goes on to what lies behind) -
+ * for rt_trace_primary, rt_trace_rays and rt_render alike, whether the materials arrive before
+ * or after the grid - and, in rt_render, the normal map, emissive factor and texture, and
+ * metallic as reflectivity. Host pointer, copied. */
 int rt_set_materials(rt_ctx* ctx, const MaterialData* materials, uint32_t n);
+
+/* TextureData of the loader (src/loaders/gltf_triangles.rs:15-19): width * height RGBA8 texels, row-major. */
+typedef struct rt_texture {
+    const uint8_t* rgba8;
+    uint32_t width, height;
+} rt_texture;
+
+/* Replaces the texture array and sampler of the renderer (src/renderer.rs:158-259): texture i becomes layer i
+ * of one Rgba8Unorm array as wide and high as the largest texture, each written to the top-left corner of its
+ * layer (the rest of a smaller texture's layer stays zero and uv still spans the whole layer, as in the
+ * reference); sampled with repeat addressing and a linear filter at mip level 0, a layer index beyond the array
+ * clamped to the last layer. n = 0 is the renderer's 1x1 white dummy. Filter arithmetic is f32:
+ * ((c00*(1-fx) + c10*fx)*(1-fy) + (c01*(1-fx) + c11*fx)*fy with c = texel/255 and fx, fy the fractions of
+ * uv*size - 0.5 (a GPU texture unit weights in fixed point, so a wgpu run can differ in a colour's last bits).
+ * Host pointers, copied. */
+int rt_set_textures(rt_ctx* ctx, const rt_texture* textures, uint32_t n);
 
 /* Replaces dispatch_workgroups + the Rgba8Unorm output texture (src/renderer.rs:822-868,
  * src/core/ray_tracing_layer.rs:436-493 which returns these bytes): ray generation, up to

@@ -89,7 +89,19 @@ class RayDebugInfo(C.Structure):
 class _Scene(C.Structure):
     _fields_ = [("boxes", C.c_void_p), ("nb", C.c_uint32), ("tris", C.c_void_p), ("nt", C.c_uint32),
                 ("meta", GridMetadata), ("cell_start", C.c_void_p), ("indices", C.c_void_p), ("n_cells", C.c_uint64),
-                ("mats", C.c_void_p), ("n_mats", C.c_uint32)]
+                ("mats", C.c_void_p), ("n_mats", C.c_uint32),
+                ("texels", C.c_void_p), ("tex_w", C.c_uint32), ("tex_h", C.c_uint32), ("tex_layers", C.c_uint32)]
+
+
+def texture_array(textures):
+    """The renderer's texture array (src/renderer.rs:196-248) from a list of (h, w, 4) uint8 textures: one layer per
+    texture, as wide and high as the largest, each texture in the top-left corner of its zero-filled layer."""
+    textures = [np.ascontiguousarray(t, np.uint8) for t in textures]
+    h, w = max(t.shape[0] for t in textures), max(t.shape[1] for t in textures)
+    arr = np.zeros((len(textures), h, w, 4), np.uint8)
+    for i, t in enumerate(textures):
+        arr[i, :t.shape[0], :t.shape[1]] = t
+    return arr
 
 
 def build(force=False):
@@ -160,6 +172,8 @@ def lib():
         L.orc_watertight_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_skin_vertices.restype = None
         L.orc_skin_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_sample_texture.restype = None
+        L.orc_sample_texture.argtypes = [C.POINTER(_Scene), C.c_float, C.c_float, C.c_int32, fp]
         L.orc_render.restype = None
         L.orc_render.argtypes = [C.POINTER(_Scene), C.POINTER(Params), C.POINTER(CameraUniform), C.c_uint32, C.c_uint32,
                                  C.POINTER(Shard), C.c_void_p, C.c_uint32, C.POINTER(RenderOpts), C.c_void_p,
@@ -407,9 +421,10 @@ class Grid:
 class Scene:
     """What a trace call needs: objects + grid (the oracle's view of the bind group)."""
 
-    def __init__(self, boxes, tris, grid=None, materials=None, **grid_kw):
+    def __init__(self, boxes, tris, grid=None, materials=None, textures=None, **grid_kw):
         self.grid = grid if grid is not None else Grid(boxes, tris, **grid_kw)
         self.materials = _c(materials, MATERIAL_DTYPE) if materials is not None else None
+        self.texels = texture_array(textures) if textures is not None and len(textures) else None
         self.boxes, self.tris = self.grid.boxes, self.grid.tris
         s = _Scene()
         s.boxes, s.nb = self.boxes.ctypes.data, len(self.boxes)
@@ -419,6 +434,9 @@ class Scene:
         s.n_cells = self.grid.n_cells
         if self.materials is not None and len(self.materials):
             s.mats, s.n_mats = self.materials.ctypes.data, len(self.materials)
+        if self.texels is not None:
+            s.texels = self.texels.ctypes.data
+            s.tex_layers, s.tex_h, s.tex_w = self.texels.shape[:3]
         self._s = s
 
 
@@ -455,6 +473,12 @@ def skin_vertices(positions, joints, weights, tri_indices, joint_matrices):
     lib().orc_skin_vertices(_ptr(positions), _ptr(joints), _ptr(weights), _ptr(tri_indices), len(tri_indices), _ptr(mats),
                             _ptr(out))
     return out
+
+
+def sample_texture(scene, u, v, layer):
+    out = (C.c_float * 4)()
+    lib().orc_sample_texture(C.byref(scene._s), u, v, layer, out)
+    return np.array(out[:], f32)
 
 
 def render(scene, cam, width, height, params=None, shard=None, materials=None, max_bounces=8, shadows=False,

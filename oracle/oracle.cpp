@@ -533,7 +533,8 @@ struct Hit {
     float t = 1e10f;
     uint32_t id = RT_MISS;
     V3 pos{0, 0, 0};
-    V3 n{0, 0, 0};
+    V3 n{0, 0, 0};        // geometric normal
+    float u = 0, v = 0;   // barycentrics of a triangle hit
 };
 
 struct FrameConsts {
@@ -603,17 +604,100 @@ inline void world_to_cell_u(V3 pos, V3 bmin, float cell, uint32_t out[3]) {
 
 inline V3 clamp3(V3 v, V3 lo, V3 hi) { return vmin(vmax(v, lo), hi); }
 
-// Alpha rules inside the shader's triangle test (raytracer_unified.wgsl:280-321) for materials without a
-// base-colour texture: MASK discards the hit when base_color.a < alpha_cutoff, BLEND when base_color.a < 0.01.
-inline bool alpha_discards(const orc_scene& s, const TriangleData& tr) {
+// ---- materials at a triangle hit: raytracer_unified.wgsl:279-366 ---------------------------------------------
+
+inline uint32_t wrap_texel(float f, uint32_t n) {
+    const int i = f2i_sat(f);
+    const int m = i % (int)n;
+    return (uint32_t)(m < 0 ? m + (int)n : m);
+}
+
+// textureSampleLevel on the renderer's array (src/renderer.rs:196-259): repeat addressing, linear filter, mip 0,
+// layer index clamped to the array. f32 weights: texel / 255, texel centres at integer + 0.5, horizontal blends
+// first.
+inline void sample_texture(const orc_scene& s, float u, float v, int32_t index, float out[4]) {
+    if (s.tex_layers == 0 || !s.texels) {
+        out[0] = out[1] = out[2] = out[3] = 1.0f;  // the 1x1 white dummy (src/renderer.rs:159-193)
+        return;
+    }
+    const uint32_t layer = index < 0 ? 0u : ((uint32_t)index < s.tex_layers ? (uint32_t)index : s.tex_layers - 1u);
+    const float x = u * (float)s.tex_w - 0.5f, y = v * (float)s.tex_h - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float fx = x - x0, fy = y - y0;
+    const uint32_t ix0 = wrap_texel(x0, s.tex_w), ix1 = wrap_texel(x0 + 1.0f, s.tex_w);
+    const uint32_t iy0 = wrap_texel(y0, s.tex_h), iy1 = wrap_texel(y0 + 1.0f, s.tex_h);
+    const uint8_t* base = s.texels + (size_t)layer * s.tex_w * s.tex_h * 4;
+    const uint8_t* c00 = base + ((size_t)iy0 * s.tex_w + ix0) * 4;
+    const uint8_t* c10 = base + ((size_t)iy0 * s.tex_w + ix1) * 4;
+    const uint8_t* c01 = base + ((size_t)iy1 * s.tex_w + ix0) * 4;
+    const uint8_t* c11 = base + ((size_t)iy1 * s.tex_w + ix1) * 4;
+    for (int k = 0; k < 4; ++k) {
+        const float top = ((float)c00[k] / 255.0f) * (1.0f - fx) + ((float)c10[k] / 255.0f) * fx;
+        const float bot = ((float)c01[k] / 255.0f) * (1.0f - fx) + ((float)c11[k] / 255.0f) * fx;
+        out[k] = top * (1.0f - fy) + bot * fy;
+    }
+}
+
+// :283-285: uv = uv0*w + uv1*u + uv2*v, w = 1 - u - v
+inline void hit_uv(const TriangleData& tr, float u, float v, float uv[2]) {
+    const float w = 1.0f - u - v;
+    uv[0] = (tr.uv0[0] * w + tr.uv1[0] * u) + tr.uv2[0] * v;
+    uv[1] = (tr.uv0[1] * w + tr.uv1[1] * u) + tr.uv2[1] * v;
+}
+
+// :288-301
+inline void base_color(const orc_scene& s, const MaterialData& m, const float uv[2], float out[4]) {
+    if (m.texture_index >= 0) {
+        float t[4];
+        sample_texture(s, uv[0], uv[1], m.texture_index, t);
+        for (int k = 0; k < 4; ++k) out[k] = t[k] * m.base_color[k];
+    } else {
+        for (int k = 0; k < 4; ++k) out[k] = m.base_color[k];
+    }
+}
+
+// Alpha rules inside the shader's triangle test (:303-316): MASK discards the hit when base_color.a < alpha_cutoff,
+// BLEND when base_color.a < 0.01. (u, v): barycentrics of the hit.
+inline bool alpha_discards(const orc_scene& s, const TriangleData& tr, float u, float v) {
     if (!s.mats) return false;
     uint32_t mat = f2u_sat(tr.material_id);
     if (mat >= s.n_mats) return false;
     const MaterialData& m = s.mats[mat];
-    if (m.texture_index >= 0) return false;
-    if (m.alpha_mode == 1u) return m.base_color[3] < m.alpha_cutoff;
-    if (m.alpha_mode == 2u) return m.base_color[3] < 0.01f;
-    return false;
+    if (m.alpha_mode != 1u && m.alpha_mode != 2u) return false;
+    float uv[2], bc[4];
+    hit_uv(tr, u, v, uv);
+    base_color(s, m, uv, bc);
+    if (m.alpha_mode == 1u) return bc[3] < m.alpha_cutoff;
+    return bc[3] < 0.01f;
+}
+
+// What the triangle test leaves in the hit besides t (:317-366): colour, normal (normal-mapped), emissive.
+struct Surface {
+    V3 color, emissive, n;
+};
+inline Surface triangle_surface(const orc_scene& s, const MaterialData& m, const TriangleData& tr, float u, float v, V3 gn) {
+    Surface sf;
+    float uv[2], bc[4];
+    hit_uv(tr, u, v, uv);
+    base_color(s, m, uv, bc);
+    sf.color = v3(bc[0], bc[1], bc[2]);
+    sf.n = gn;
+    if (m.normal_texture_index >= 0) {  // :319-348
+        float ns[4];
+        sample_texture(s, uv[0], uv[1], m.normal_texture_index, ns);
+        const V3 tn = normalize(v3(ns[0] * 2.0f - 1.0f, ns[1] * 2.0f - 1.0f, ns[2] * 2.0f - 1.0f));
+        const V3 up = fabsf(gn.y) > 0.9f ? v3(0.0f, 0.0f, 1.0f) : v3(0.0f, 1.0f, 0.0f);
+        const V3 tangent = normalize(cross(up, gn));
+        const V3 bitangent = cross(gn, tangent);
+        sf.n = normalize((tangent * tn.x + bitangent * tn.y) + gn * tn.z);
+    }
+    sf.emissive = ld(m.emissive);
+    if (m.emissive_texture_index >= 0) {  // :350-362
+        float es[4];
+        sample_texture(s, uv[0], uv[1], m.emissive_texture_index, es);
+        sf.emissive = v3(sf.emissive.x * es[0], sf.emissive.y * es[1], sf.emissive.z * es[2]);
+    }
+    return sf;
 }
 
 // raytracer_unified.wgsl:430-588, geometry only. any_hit: stop at the first accepted intersection.
@@ -707,13 +791,15 @@ Hit trace_ray(const orc_scene& s, const rt_params& p, const CameraUniform& cam, 
                     ctr.tri++;
                     const TriangleData& tr = s.tris[ti];
                     TriHit th;
-                    if (moller_trumbore(o, d, ld(tr.v0), ld(tr.v1), ld(tr.v2), wgsl, &th) && !alpha_discards(s, tr)) {
+                    if (moller_trumbore(o, d, ld(tr.v0), ld(tr.v1), ld(tr.v2), wgsl, &th) && !alpha_discards(s, tr, th.u, th.v)) {
                         Hit h;
                         h.hit = true;
                         h.t = th.t;
                         h.id = obj;
                         h.pos = o + d * th.t;
                         h.n = th.n;
+                        h.u = th.u;
+                        h.v = th.v;
                         if (consider(h)) return closest;
                     }
                 }
@@ -887,8 +973,8 @@ extern "C" void orc_skin_vertices(const float* positions, const uint16_t* joints
 }
 
 // ---- shaded picture: raytracer_unified.wgsl:590-621 (sky, lighting), :655-720 (bounce loop, debug pixel,
-// texture store), :230-233 (box colour), :280-303,345-370 (untextured material). Textures, normal maps and the
-// alpha modes are not restated (the GPU path does not evaluate them either).
+// texture store), :230-233 (box colour), :279-366 (triangle material: base-colour texture, normal map, emissive
+// texture; the alpha rules are part of trace_ray above).
 namespace {
 
 inline uint32_t unorm8(float c) {
@@ -906,6 +992,10 @@ inline bool near_grid_boundary(const orc_scene& s, V3 pos, float threshold) {
 }
 
 }  // namespace
+
+extern "C" void orc_sample_texture(const orc_scene* s, float u, float v, int32_t layer, float out_rgba[4]) {
+    sample_texture(*s, u, v, layer, out_rgba);
+}
 
 extern "C" void orc_render(const orc_scene* s, const rt_params* p, const CameraUniform* cam, uint32_t width, uint32_t height,
                            const rt_shard* shard, const MaterialData* mats, uint32_t n_mats, const rt_render_opts* opts,
@@ -953,10 +1043,13 @@ extern "C" void orc_render(const orc_scene* s, const rt_params* p, const CameraU
                             color = ld(s->boxes[h.id].color);
                             refl = s->boxes[h.id].reflectivity;
                         } else {
-                            uint32_t mat = f2u_sat(s->tris[h.id - s->nb].material_id);
+                            const TriangleData& tr = s->tris[h.id - s->nb];
+                            uint32_t mat = f2u_sat(tr.material_id);
                             if (mat < n_mats) {
-                                color = v3(mats[mat].base_color[0], mats[mat].base_color[1], mats[mat].base_color[2]);
-                                emissive = ld(mats[mat].emissive);
+                                const Surface sf = triangle_surface(*s, mats[mat], tr, h.u, h.v, h.n);
+                                color = sf.color;
+                                emissive = sf.emissive;
+                                h.n = sf.n;  // the normal-mapped normal is the hit's normal from here on (:347)
                                 refl = mats[mat].metallic;
                             }
                         }
@@ -1083,7 +1176,7 @@ extern "C" void orc_trace_rays_bruteforce(const orc_scene* s, const rt_params* p
             for (uint32_t k = 0; k < s->nt; ++k) {
                 const TriangleData& tr = s->tris[k];
                 TriHit th;
-                if (moller_trumbore(o, d, ld(tr.v0), ld(tr.v1), ld(tr.v2), wgsl, &th) && th.t < best && !alpha_discards(*s, tr)) {
+                if (moller_trumbore(o, d, ld(tr.v0), ld(tr.v1), ld(tr.v2), wgsl, &th) && th.t < best && !alpha_discards(*s, tr, th.u, th.v)) {
                     best = th.t;
                     id = s->nb + k;
                 }

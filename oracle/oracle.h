@@ -15,7 +15,8 @@
  *   examples/massive_benchmark.rs:226-270,311-342, src/core/benchmark.rs:99-140,
  *   benches/bounding_volumes.rs:39-47,147-179
  * and, because the reference has no CPU grid traversal, of the geometry part of
- *   src/raytracer_unified.wgsl:147-235,238-277,381-409,430-588,625-653.
+ *   src/raytracer_unified.wgsl:147-235,238-277,381-409,430-588,625-653, and of the material part of the
+ * triangle test (:279-366) against the texture array of src/renderer.rs:158-259.
  * Vector arithmetic follows glam 0.29.3's scalar Vec3 (Cargo.lock:1077-1078; source not
  * vendored in the reference): dot = (x*x' + y*y') + z*z', cross = (y*z' - y'*z, ...),
  * normalize = v * (1/sqrt(dot)), min/max component-wise f32::min/f32::max.
@@ -93,7 +94,17 @@ typedef struct orc_scene {
     uint64_t n_cells;
     const MaterialData* mats; /* may be NULL: the "Materials" buffer, for the alpha rules of the triangle test */
     uint32_t n_mats;
+    /* The texture array as the renderer builds it (src/renderer.rs:196-248): tex_layers layers of tex_w x tex_h RGBA8
+     * texels, each source texture in the top-left corner of its layer, the rest zero. tex_layers == 0: the 1x1 white
+     * dummy (:159-193). */
+    const uint8_t* texels;
+    uint32_t tex_w, tex_h, tex_layers;
 } orc_scene;
+
+/* textureSampleLevel(texture_array, sampler, uv, layer, 0.0) with the renderer's sampler (repeat, linear, src/renderer.rs:251-259),
+ * filter weights in f32 (see rt_set_textures in rt_mi355.h). Parity unpinned by the reference (no texture test or fixture);
+ * pinned by hand-computed known answers in tests/test_oracle_textures.py. */
+void orc_sample_texture(const orc_scene* s, float u, float v, int32_t layer, float out_rgba[4]);
 
 /* Primary (+ optional shadow) rays for the pixels selected by shard (NULL = whole frame);
  * outputs packed exactly as rt_trace_primary packs them. shadow_o/shadow_d (optional,
@@ -105,7 +116,8 @@ void orc_trace_primary(const orc_scene* s, const rt_params* p, const CameraUnifo
  * build's own kernel, not a reference routine: parity unpinned by the reference). out_xyz9: n_triangles*9. */
 void orc_skin_vertices(const float* positions, const uint16_t* joints, const float* weights, const uint32_t* tri_indices,
                        uint32_t n_triangles, const float* joint_matrices, float* out_xyz9);
-/* The shaded picture of the shader's main() (raytracer_unified.wgsl:590-621, 655-720) with untextured materials;
+/* The shaded picture of the shader's main() (raytracer_unified.wgsl:590-621, 655-720), materials as the triangle
+ * test evaluates them (:279-366: base-colour texture, alpha rules, normal map, emissive texture, metallic);
  * 4 bytes per pixel, packed like orc_trace_primary's records. Parity unpinned by the reference (it has no image
  * fixture); pinned against itself by tests/test_oracle_golden.py. */
 void orc_render(const orc_scene* s, const rt_params* p, const CameraUniform* cam, uint32_t width, uint32_t height,

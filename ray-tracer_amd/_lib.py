@@ -74,6 +74,11 @@ class RtBvhStats(C.Structure):
                 ("total_primitives", C.c_uint64)]
 
 
+class RtTexture(C.Structure):
+    """rt_texture: TextureData of the reference's loader (src/loaders/gltf_triangles.rs:15-19)."""
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
 class RtRenderOpts(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("shadows", C.c_uint32), ("debug_enabled", C.c_uint32),
                 ("debug_pixel", C.c_uint32 * 2), ("_pad", C.c_uint32 * 3)]
@@ -118,6 +123,7 @@ PROTOTYPES = {
     "rt_assemble_tiles_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
     "rt_default_render_opts": (None, [C.POINTER(RtRenderOpts)]),
     "rt_set_materials": (_I, [_VP, _VP, _U32]),
+    "rt_set_textures": (_I, [_VP, _VP, _U32]),
     "rt_render": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), C.POINTER(RtRenderOpts), _VP]),
     "rt_debug_pixel": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, _U32, _U32, C.POINTER(RayDebugInfo)]),
     "rt_get_stats": (_I, [_VP, C.POINTER(RtStats)]),

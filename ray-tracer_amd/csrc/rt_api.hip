@@ -38,9 +38,11 @@ __global__ void k_emit_cells(const uint32_t* __restrict__ cell_start, uint32_t g
     cells[p] = rec;
 }
 
-// The id word of every triangle reference, given the materials: a triangle whose material discards all of its
-// hits keeps its record (the shader tests it) but can never be accepted. Only materials without a base-colour
-// texture can be judged here (raytracer_unified.wgsl:291-321); textured ones stay visible.
+// The id word and the material word of every triangle reference, given the materials. A triangle whose material
+// discards all of its hits (constant alpha below the MASK cutoff / the BLEND threshold, no base-colour texture,
+// raytracer_unified.wgsl:291-316) keeps its record (the shader tests it) but can never be accepted. A triangle
+// whose alpha comes from a base-colour texture carries material + 1 in the spare word of its third quad: the
+// trace evaluates the rule per hit.
 __global__ void k_ref_visibility(const uint32_t* __restrict__ indices, uint32_t n_refs, uint32_t nb, uint32_t nt,
                                  const uint32_t* __restrict__ tri_mat, const float4* __restrict__ materials,
                                  uint32_t n_materials, float4* __restrict__ refs) {
@@ -48,15 +50,20 @@ __global__ void k_ref_visibility(const uint32_t* __restrict__ indices, uint32_t 
     if (r >= n_refs) return;
     const uint32_t id = indices[r];
     if (id < nb || id - nb >= nt) return;
-    uint32_t word = id;
+    uint32_t word = id, mat_word = 0;
     const uint32_t mat = tri_mat[id - nb];
     if (mat < n_materials) {
         const float4 m0 = materials[4 * mat], m1 = materials[4 * mat + 1], m3 = materials[4 * mat + 3];
         const int texture = (int)__float_as_uint(m1.w);
         const uint32_t mode = __float_as_uint(m3.x);
-        if (texture < 0 && ((mode == 1u && m0.w < m3.y) || (mode == 2u && m0.w < 0.01f))) word = REF_INVISIBLE;
+        if (texture < 0) {
+            if ((mode == 1u && m0.w < m3.y) || (mode == 2u && m0.w < 0.01f)) word = REF_INVISIBLE;
+        } else if (mode == 1u || mode == 2u) {
+            mat_word = mat + 1u;
+        }
     }
     refs[3 * (size_t)r].w = __uint_as_float(word);
+    refs[3 * (size_t)r + 2].w = __uint_as_float(mat_word);
 }
 
 // One 48-byte record per reference, in cell order.
@@ -149,7 +156,7 @@ __global__ void k_tri_normals(const float* __restrict__ tri_v, uint32_t first, u
 }
 
 __global__ void k_tri_unpack(const TriangleData* __restrict__ tris, uint32_t nt, float* __restrict__ tri_v,
-                             uint32_t* __restrict__ tri_mat) {
+                             uint32_t* __restrict__ tri_mat, float* __restrict__ tri_uv) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nt) return;
     const TriangleData t = tris[i];
@@ -158,6 +165,8 @@ __global__ void k_tri_unpack(const TriangleData* __restrict__ tris, uint32_t nt,
     o[0] = t.v0[0], o[1] = t.v0[1], o[2] = t.v0[2];
     o[3] = t.v1[0], o[4] = t.v1[1], o[5] = t.v1[2];
     o[6] = t.v2[0], o[7] = t.v2[1], o[8] = t.v2[2];
+    float* uv = tri_uv + 6 * (size_t)i;
+    uv[0] = t.uv0[0], uv[1] = t.uv0[1], uv[2] = t.uv1[0], uv[3] = t.uv1[1], uv[4] = t.uv2[0], uv[5] = t.uv2[1];
 }
 
 template <bool WGSL>
@@ -252,6 +261,14 @@ DevScene make_scene(const rt_ctx* c) {
     }
     s.cell_size = c->meta.finest_cell_size;
     s.inv_cell_size = 1.0f / fmaxf(s.cell_size, 1e-8f);  // raytracer_unified.wgsl:384
+    s.tex.texels = c->texels.as<uchar4>();
+    s.tex.w = c->tex_w;
+    s.tex.h = c->tex_h;
+    s.tex.layers = c->tex_layers;
+    s.tex.tri_uv = c->tri_uv.as<float>();
+    s.tex.tri_mat = c->tri_mat.as<uint32_t>();
+    s.tex.materials = c->materials.as<float4>();
+    s.tex.n_materials = c->n_materials;
     return s;
 }
 
@@ -327,8 +344,13 @@ int fetch_stats(rt_ctx* c) {
     return RT_OK;
 }
 
+// True when the trace kernels cannot address the grid through buffer descriptors (32-bit byte offsets).
+bool wide_grid(const DevScene& s) {
+    return ((uint64_t)s.n_refs + 1) * 48 > 0xFFFFFFFFull || (uint64_t)s.n_bordered * 8 > 0xFFFFFFFFull;
+}
+
 // Kernel variants: WGSL (constant set), SHADOW / ANY, BOXES (scene has boxes). The counting build is the
-// general one (with the box path).
+// general one (with the box path); so are the builds for textured alpha and for grids of 4 GiB and more.
 template <bool WGSL, bool SHADOW>
 void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* op,
                     uint2* os) {
@@ -344,7 +366,17 @@ void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const D
         }
     }
 #endif
-    if (stats)
+    if (wide_grid(s)) {
+        if (stats)
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        else
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+    } else if (c->tex_mode == 2) {  // hits decided by a texture's alpha: the general kernel with the material path
+        if (stats)
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        else
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+    } else if (stats)
         hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
     else if (s.nb != 0)
         hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
@@ -356,7 +388,17 @@ template <bool WGSL, bool ANY>
 void launch_rays(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const float* o, const float* d, uint32_t n,
                  uint2* out) {
     unsigned long long* st = c->stats.as<unsigned long long>();
-    if (stats)
+    if (wide_grid(s)) {
+        if (stats)
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+        else
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+    } else if (c->tex_mode == 2) {
+        if (stats)
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+        else
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+    } else if (stats)
         hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
     else if (s.nb != 0)
         hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
@@ -490,7 +532,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
                       &c->skin_weights, &c->skin_tri, &c->skin_mats, &c->bvh_nodes, &c->bvh_leaf_first, &c->bvh_prims, &c->bvh_recs,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
                       &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->b_obj_n, &c->b_obj_off, &c->b_obj_sum, &c->out_p,     &c->out_s,
-                      &c->in_o,      &c->in_d,      &c->stats,      &c->misc};
+                      &c->in_o,      &c->in_d,      &c->stats,      &c->misc,      &c->tri_uv,    &c->texels};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -584,8 +626,9 @@ extern "C" int rt_set_scene(rt_ctx* c, const BoxData* boxes, uint32_t nb, const 
         RT_HIP(c, c->misc.reserve((size_t)nt * sizeof(TriangleData)));
         RT_HIP(c, hipMemcpyAsync(c->misc.p, tris, (size_t)nt * sizeof(TriangleData), hipMemcpyHostToDevice, c->stream));
         RT_HIP(c, c->tri_mat.reserve((size_t)nt * sizeof(uint32_t)));
+        RT_HIP(c, c->tri_uv.reserve((size_t)nt * 6 * sizeof(float)));
         hipLaunchKernelGGL(k_tri_unpack, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->misc.as<TriangleData>(), nt,
-                           c->tri_v.as<float>(), c->tri_mat.as<uint32_t>());
+                           c->tri_v.as<float>(), c->tri_mat.as<uint32_t>(), c->tri_uv.as<float>());
         RT_HIP(c, hipGetLastError());
         RT_HIP(c, c->tri_n.reserve((size_t)nt * sizeof(float4)));
         hipLaunchKernelGGL(k_tri_normals, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->tri_v.as<float>(), 0u, nt,
@@ -928,12 +971,49 @@ extern "C" int rt_read_vertices(rt_ctx* c, float* xyz9) {
 extern "C" int rt_set_materials(rt_ctx* c, const MaterialData* materials, uint32_t n) {
     if (int r = use(c)) return r;
     if (n && !materials) return fail(c, RT_ERR_INVALID, "rt_set_materials: NULL array with non-zero count");
+    if (n > 0x7FFFFFFFu) return fail(c, RT_ERR_LIMIT, "rt_set_materials: more than 2^31-1 materials");
     if (int r = scene_barrier(c)) return r;
     RT_HIP(c, c->materials.reserve((size_t)n * sizeof(MaterialData) + 16));
     if (n) RT_HIP(c, hipMemcpyAsync(c->materials.p, materials, (size_t)n * sizeof(MaterialData), hipMemcpyHostToDevice, c->stream));
     c->n_materials = n;
+    c->tex_mode = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const MaterialData& m = materials[i];
+        if (m.texture_index >= 0 && (m.alpha_mode == 1u || m.alpha_mode == 2u)) c->tex_mode = 2;
+        if (c->tex_mode < 1 && (m.texture_index >= 0 || m.normal_texture_index >= 0 || m.emissive_texture_index >= 0))
+            c->tex_mode = 1;
+    }
     if (c->has_grid)
         if (int r = apply_visibility(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_set_textures(rt_ctx* c, const rt_texture* textures, uint32_t n) {
+    if (int r = use(c)) return r;
+    if (n && !textures) return fail(c, RT_ERR_INVALID, "rt_set_textures: NULL array with non-zero count");
+    uint32_t w = 0, h = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!textures[i].rgba8 || !textures[i].width || !textures[i].height)
+            return fail(c, RT_ERR_INVALID, "rt_set_textures: texture %u is empty", i);
+        w = textures[i].width > w ? textures[i].width : w;
+        h = textures[i].height > h ? textures[i].height : h;
+    }
+    if (n && ((uint64_t)w * h * n > 0x40000000ull || w > 16384u || h > 16384u))
+        return fail(c, RT_ERR_LIMIT, "rt_set_textures: %u layers of %u x %u texels (max 16384 a side, 2^30 texels in all)", n, w, h);
+    if (int r = scene_barrier(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    // the array as the renderer builds it: every layer max_w x max_h, zero, texture in its top-left corner
+    const size_t layer = (size_t)w * h * 4;
+    RT_HIP(c, c->texels.reserve(layer * n + 16));
+    if (n) RT_HIP(c, hipMemsetAsync(c->texels.p, 0, layer * n, c->stream));
+    for (uint32_t i = 0; i < n; ++i)
+        RT_HIP(c, hipMemcpy2DAsync(static_cast<uint8_t*>(c->texels.p) + layer * i, (size_t)w * 4, textures[i].rgba8,
+                                   (size_t)textures[i].width * 4, (size_t)textures[i].width * 4, textures[i].height,
+                                   hipMemcpyHostToDevice, c->stream));
+    c->tex_w = w;
+    c->tex_h = h;
+    c->tex_layers = n;
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
@@ -987,7 +1067,13 @@ extern "C" int rt_render(rt_ctx* c, const CameraUniform* cam, uint32_t width, ui
     unsigned long long* st = stats ? c->stats.as<unsigned long long>() : nullptr;
     const dim3 grid((uint32_t)blocks);
     const bool wgsl = c->params.wgsl_compat != 0, has_boxes = s.nb != 0;
-    if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+    if (wide_grid(s)) {
+        if (wgsl) hipLaunchKernelGGL((k_render<true, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+        else hipLaunchKernelGGL((k_render<false, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+    } else if (c->tex_mode != 0) {  // materials name textures: the general kernel with the material path
+        if (wgsl) hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+        else hipLaunchKernelGGL((k_render<false, true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+    } else if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
     else if (wgsl) hipLaunchKernelGGL((k_render<true, false>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
     else if (has_boxes) hipLaunchKernelGGL((k_render<false, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
     else hipLaunchKernelGGL((k_render<false, false>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
@@ -1010,10 +1096,15 @@ extern "C" int rt_debug_pixel(rt_ctx* c, const CameraUniform* cam, uint32_t widt
     RT_HIP(c, c->misc.reserve(sizeof(RayDebugInfo)));
     const DevScene s = make_scene(c);
     const DevFrame f = make_frame(c, cam, width, height);
-    if (c->params.wgsl_compat)
-        hipLaunchKernelGGL(k_debug_pixel<true>, dim3(1), dim3(64), 0, c->stream, s, f, px, py, c->misc.as<float>());
+    const bool wide = wide_grid(s);
+    if (c->params.wgsl_compat && wide)
+        hipLaunchKernelGGL((k_debug_pixel<true, true>), dim3(1), dim3(64), 0, c->stream, s, f, px, py, c->misc.as<float>());
+    else if (c->params.wgsl_compat)
+        hipLaunchKernelGGL((k_debug_pixel<true>), dim3(1), dim3(64), 0, c->stream, s, f, px, py, c->misc.as<float>());
+    else if (wide)
+        hipLaunchKernelGGL((k_debug_pixel<false, true>), dim3(1), dim3(64), 0, c->stream, s, f, px, py, c->misc.as<float>());
     else
-        hipLaunchKernelGGL(k_debug_pixel<false>, dim3(1), dim3(64), 0, c->stream, s, f, px, py, c->misc.as<float>());
+        hipLaunchKernelGGL((k_debug_pixel<false>), dim3(1), dim3(64), 0, c->stream, s, f, px, py, c->misc.as<float>());
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipMemcpyAsync(info, c->misc.p, sizeof(RayDebugInfo), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));

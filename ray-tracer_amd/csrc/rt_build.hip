@@ -367,12 +367,20 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
         hipLaunchKernelGGL(k_bin<true>, pair_grid, dim3(256), 0, st, g, c->boxes.as<BoxData>(), c->tri_v.as<float>(),
                            (const uint32_t*)obj_off, n_tmp, cursor, (const uint32_t*)tmp_start, tmp_ids, tmp_cell);
         RT_HIP(c, hipGetLastError());
+        // rocPRIM's segmented sort launches work per segment and stops sorting (without an error) from about 2^25
+        // segments on, so the cells go through it in batches; offsets stay absolute, so every batch addresses the
+        // same two key arrays.
+        const uint32_t batch = 1u << 24;
         size_t sort_bytes = 0;
-        RT_HIP(c, rocprim::segmented_radix_sort_keys(nullptr, sort_bytes, tmp_ids, tmp_sorted, n_tmp, n_cells, tmp_start,
-                                                     tmp_start + 1, 0, 32, st));
-        RT_HIP(c, c->b_scan_tmp.reserve(sort_bytes + 256));
-        RT_HIP(c, rocprim::segmented_radix_sort_keys(c->b_scan_tmp.p, sort_bytes, tmp_ids, tmp_sorted, n_tmp, n_cells,
+        RT_HIP(c, rocprim::segmented_radix_sort_keys(nullptr, sort_bytes, tmp_ids, tmp_sorted, n_tmp, std::min(n_cells, batch),
                                                      tmp_start, tmp_start + 1, 0, 32, st));
+        RT_HIP(c, c->b_scan_tmp.reserve(sort_bytes + 256));
+        for (uint32_t first = 0; first < n_cells; first += batch) {
+            const uint32_t n = std::min(batch, n_cells - first);
+            size_t bytes = sort_bytes;
+            RT_HIP(c, rocprim::segmented_radix_sort_keys(c->b_scan_tmp.p, bytes, tmp_ids, tmp_sorted, n_tmp, n, tmp_start + first,
+                                                         tmp_start + first + 1, 0, 32, st));
+        }
 
         // ---- cap: keep the first max_per_cell ids of every cell, compact
         hipLaunchKernelGGL(k_clamp_counts, dim3((n_cells + 1 + 255) / 256), dim3(256), 0, st, counts, n_cells, max_per_cell,

@@ -61,8 +61,14 @@ struct rt_ctx {
     rt::DevBuf tri_v;  // float[nt*9]: v0,v1,v2
     rt::DevBuf tri_n;  // float4[nt]: geometric normal
     rt::DevBuf tri_mat;    // u32[nt]: u32(TriangleData::material_id)
+    rt::DevBuf tri_uv;     // float[nt*6]: uv0, uv1, uv2
     rt::DevBuf materials;  // MaterialData[n_materials]
     uint32_t n_materials = 0;
+    // 0: no material names a texture; 1: some do (the shaded picture samples); 2: some decide a hit's
+    // acceptance by a texture's alpha (every trace kernel samples)
+    int tex_mode = 0;
+    rt::DevBuf texels;     // uchar4[tex_layers][tex_h][tex_w]
+    uint32_t tex_w = 0, tex_h = 0, tex_layers = 0;
     // skin (rt_set_skin): per-vertex bind position, joint indices, weights; per-triangle vertex indices
     rt::DevBuf skin_pos, skin_joints, skin_weights, skin_tri, skin_mats;
     uint32_t skin_nv = 0, skin_max_joint = 0;

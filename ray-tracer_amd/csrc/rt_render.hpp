@@ -3,10 +3,10 @@
 // highlight and the texture store of main (:655-720), box colours (:230-233) and the untextured part of the
 // triangle material (:280-303, :345-364).
 //
-// The alpha MASK / BLEND rejection inside the triangle test (:310-321) is applied to the reference records when
-// materials are set (k_ref_visibility in rt_api.hip), for materials without a base-colour texture.
-// Not here yet: texture sampling, normal maps, emissive textures. A material that names textures is shaded with its
-// constant factors alone and never discards a hit.
+// The alpha MASK / BLEND rejection inside the triangle test (:303-316) happens in the trace: for materials with a
+// constant alpha it is folded into the reference records when materials are set (k_ref_visibility in rt_api.hip),
+// for a textured alpha trace_ray<TEX> samples per hit. TEX here: materials name textures, so the winning hit's
+// material is evaluated at its interpolated uv (base-colour texture, normal map, emissive texture: rt_texture.hpp).
 //
 // Same numerics contract as the trace: the reference's f32 expression trees, no contraction, host-evaluated
 // transcendental constants. The 8-bit store is round-to-nearest-even of clamp(c, 0, 1) * 255 (NaN -> 0).
@@ -41,7 +41,7 @@ __device__ inline bool near_grid_boundary(const DevScene& s, V3 pos, float thres
     return dx < threshold || dy < threshold || dz < threshold;
 }
 
-template <bool WGSL, bool BOXES>
+template <bool WGSL, bool BOXES, bool TEX = false, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
                                                 unsigned long long* stats) {
     const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap
             const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
             HitRec h;
             n_rays++;
-            if (!trace_ray<WGSL, false, false, BOXES>(s, o, rd, h, ctr)) {
+            if (!trace_ray<WGSL, false, false, BOXES, TEX, WIDE>(s, o, rd, h, ctr)) {
                 // sky (:591-596)
                 const float t = (d.y + 1.0f) * 0.5f;
                 acc = acc + mix(v3(0.3f, 0.5f, 0.7f), v3(0.5f, 0.7f, 1.0f), t) * mult;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap
             }
             if (bounce == 0) n_ph++;
             const V3 pos = o + d * h.t;
-            const V3 n = hit_normal(s, h, pos);
+            V3 n = hit_normal(s, h, pos);
             V3 color = v3(0.7f, 0.7f, 0.7f), emissive = v3(0.0f, 0.0f, 0.0f);
             float refl = 0.0f;
             if (BOXES && h.ref == MISS) {
@@ -91,6 +91,17 @@ __global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap
                     color = v3(m0.x, m0.y, m0.z);
                     emissive = v3(m1.x, m1.y, m1.z);
                     refl = m2.x;  // metallic (:361)
+                    if (TEX) {
+                        const float4 c0 = s.refs[3 * (size_t)h.ref], c1 = s.refs[3 * (size_t)h.ref + 1],
+                                     c2 = s.refs[3 * (size_t)h.ref + 2];
+                        float bu, bv;
+                        hit_barycentrics(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z), v3(c2.x, c2.y, c2.z), bu, bv);
+                        const F2 uv = hit_uv(s.tex, h.id - s.nb, bu, bv);
+                        const float4 bc = base_color(s.tex, mat, uv);
+                        color = v3(bc.x, bc.y, bc.z);
+                        n = mapped_normal(s.tex, mat, uv, n);
+                        emissive = emissive_color(s.tex, mat, uv);
+                    }
                 }
             }
             // lighting (:598-603)
@@ -101,7 +112,7 @@ __global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap
                 HitRec oh;
                 n_rays++;
                 n_sr++;
-                if (trace_ray<WGSL, true, false, BOXES>(s, pos + nf * f.shadow_offset, f.shadow, oh, ctr)) {
+                if (trace_ray<WGSL, true, false, BOXES, TEX, WIDE>(s, pos + nf * f.shadow_offset, f.shadow, oh, ctr)) {
                     n_sh++;
                     diffuse = 0.0f;
                 }

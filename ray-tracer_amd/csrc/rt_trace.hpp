@@ -16,7 +16,10 @@
 //                 (centre.xyz, 0) (half.xyz, 0) with lo/hi = interpolated centre -/+ half
 #pragma once
 
+#include <type_traits>
+
 #include "rt_math.hpp"
+#include "rt_texture.hpp"
 
 namespace rt {
 
@@ -42,6 +45,7 @@ struct DevScene {
     float bmin[3], bmax[3];
     float cell_size;
     float inv_cell_size;  // 1 / max(cell_size, 1e-8), evaluated once on the host
+    DevTex tex;           // materials and textures, for hits whose acceptance depends on a texture's alpha
 };
 
 // Direction-dependent constants of a ray (raytracer_unified.wgsl:494-515). Per lane for primary rays; for shadow
@@ -140,16 +144,38 @@ __device__ inline uint2 buf_load8(v4i rsrc, uint32_t index) {
 // ANY: stop at the first accepted intersection. BOXES: scene has boxes (pre-pass + box candidates).
 // STATS: count what the REFERENCE algorithm does (no skipping), for parity of the counters and for the
 // algorithmic byte count. Returns true on a hit.
+// TEX: the scene has materials whose alpha comes from a texture; a reference to such a triangle carries its material
+// in the spare word of the third quad, and a geometric hit that would become the closest one is first put to the
+// shader's alpha rule (raytracer_unified.wgsl:303-316) at its interpolated uv. (The shader applies the rule inside
+// the triangle test, before comparing distances; a discarded or a farther hit changes nothing either way.)
+// WIDE: the reference records or the cell array span 4 GiB or more. A buffer descriptor forms its byte offset
+// (index * stride) in 32 bits, so such arrays are read through plain 64-bit pointers instead.
 // X: development switch (0 in every shipped instantiation).
-template <bool WGSL, bool ANY, bool STATS, bool BOXES, int X = 0>
+template <bool WGSL, bool ANY, bool STATS, bool BOXES, bool TEX = false, bool WIDE = false, int X = 0>
 __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitRec& out, Counters& ctr) {
     constexpr bool SKIP = !STATS;
     float closest = 1e10f;
     uint32_t best_id = MISS, best_ref = MISS;
     const V3 d = rd.d, inv = rd.inv;
     const RayPk rp = make_ray_pk(o, d);
-    const v4i refs = make_rsrc(s.refs, 48, s.n_refs + 1);
-    const v4i cells = make_rsrc(s.cells, 8, s.n_bordered);
+    const v4i refs_d = make_rsrc(s.refs, 48, s.n_refs + 1);
+    const v4i cells_d = make_rsrc(s.cells, 8, s.n_bordered);
+    auto ref_quad = [&](uint32_t r, auto quad) -> float4 {
+        constexpr int Q = decltype(quad)::value;
+        if constexpr (WIDE)
+            return s.refs[3 * (size_t)r + Q];
+        else
+            return buf_load16<16 * Q>(refs_d, r);
+    };
+    auto cell_rec = [&](uint32_t idx) -> uint2 {
+        if constexpr (WIDE)
+            return s.cells[idx];
+        else
+            return buf_load8(cells_d, idx);
+    };
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
     if (STATS) ctr.steps = 0;
 
     // moving boxes are tested directly, before the grid (:442-461)
@@ -231,6 +257,13 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             if (STATS && id != REF_INVALID) ctr.tri++;
             const float t = moller_trumbore_pk<WGSL>(rp, c0, c1, c2);
             if (t > 0.0f && t < closest && id < REF_INVISIBLE) {
+                if (TEX && __float_as_uint(c2.w) != 0u) {
+                    const uint32_t mat = __float_as_uint(c2.w) - 1u;
+                    float bu, bv;
+                    hit_barycentrics(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z), v3(c2.x, c2.y, c2.z), bu, bv);
+                    const float4 bc = base_color(s.tex, mat, hit_uv(s.tex, id - s.nb, bu, bv));
+                    if (alpha_discards(s.tex, mat, bc.w)) return false;
+                }
                 closest = t;
                 best_id = id;
                 best_ref = r;
@@ -245,12 +278,12 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     // stays inside the array (padded by one record) and its result is not used.
     auto scan = [&](uint32_t r, uint32_t n) {
         const uint32_t r_end = r + n;
-        float4 a0 = buf_load16<0>(refs, r), a1 = buf_load16<16>(refs, r), a2 = buf_load16<32>(refs, r);
+        float4 a0 = ref_quad(r, Q0{}), a1 = ref_quad(r, Q1{}), a2 = ref_quad(r, Q2{});
         for (;;) {
-            const float4 b0 = buf_load16<0>(refs, r + 1), b1 = buf_load16<16>(refs, r + 1), b2 = buf_load16<32>(refs, r + 1);
+            const float4 b0 = ref_quad(r + 1, Q0{}), b1 = ref_quad(r + 1, Q1{}), b2 = ref_quad(r + 1, Q2{});
             if (test(a0, a1, a2, r)) break;
             if (++r == r_end) break;
-            a0 = buf_load16<0>(refs, r + 1), a1 = buf_load16<16>(refs, r + 1), a2 = buf_load16<32>(refs, r + 1);
+            a0 = ref_quad(r + 1, Q0{}), a1 = ref_quad(r + 1, Q1{}), a2 = ref_quad(r + 1, Q2{});
             if (test(b0, b1, b2, r)) break;
             if (++r == r_end) break;
         }
@@ -270,7 +303,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             uint32_t n = 0, first = 0;
             if (fi < s.n_cells) {
                 const uint32_t x = fi % s.gx, y = (fi / s.gx) % s.gy, z = fi / (s.gx * s.gy);
-                const uint2 cell = buf_load8(cells, (x + 1u) + (y + 1u) * s.px + (z + 1u) * s.pxy);
+                const uint2 cell = cell_rec((x + 1u) + (y + 1u) * s.px + (z + 1u) * s.pxy);
                 first = cell.x;
                 n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
             }
@@ -303,7 +336,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     // step leaves the grid" (:568-583) is "the cell just fetched is a sentinel": no coordinates, no per-axis
     // counters and no range check on the index.
     uint32_t idx = (cx + 1u) + (cy + 1u) * s.px + (cz + 1u) * s.pxy;
-    uint2 cell = buf_load8(cells, idx);
+    uint2 cell = cell_rec(idx);
     for (uint32_t i = 0; i < s.max_steps; ++i) {
         // The step this iteration ends with (:566-587: x if tx < ty and tx < tz, else y if ty < tz, else z)
         // depends on t_max only; deciding it here keeps it off the candidate loop's exit path and gives the
@@ -329,7 +362,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         t_max.x += ax ? t_delta.x : 0.0f;
         t_max.y += ay ? t_delta.y : 0.0f;
         t_max.z += az ? t_delta.z : 0.0f;
-        cell = buf_load8(cells, idx);
+        cell = cell_rec(idx);
     }
     out = HitRec{closest, best_id, best_ref};
     return best_id != MISS;
@@ -379,7 +412,7 @@ __device__ inline void flush_stats(unsigned long long* stats, unsigned long long
 // different XCDs at the same time: cheap (sky) and expensive (dense geometry) image regions are spread
 // evenly over the chip. (Giving each XCD one contiguous band of the image instead left most XCDs idle
 // behind the one that owned the geometry: 30 % average occupancy on the headline frame.)
-template <bool WGSL, bool SHADOW, bool STATS, bool BOXES>
+template <bool WGSL, bool SHADOW, bool STATS, bool BOXES, bool TEX = false, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
                                                        uint2* __restrict__ out_s, unsigned long long* stats) {
     const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
@@ -403,7 +436,7 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
         const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
         HitRec h;
         n_rays++;
-        if (trace_ray<WGSL, false, STATS, BOXES>(s, o, rd, h, ctr)) {
+        if (trace_ray<WGSL, false, STATS, BOXES, TEX, WIDE>(s, o, rd, h, ctr)) {
             n_ph++;
             ph = make_uint2(h.id, __float_as_uint(h.t));
             if (SHADOW) {
@@ -414,7 +447,7 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
                 HitRec oh;
                 n_rays++;
                 n_sr++;
-                if (trace_ray<WGSL, true, STATS, BOXES>(s, so, f.shadow, oh, ctr)) {
+                if (trace_ray<WGSL, true, STATS, BOXES, TEX, WIDE>(s, so, f.shadow, oh, ctr)) {
                     n_sh++;
                     sh = make_uint2(oh.id, __float_as_uint(oh.t));
                 }
@@ -430,7 +463,7 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
 }
 
 // Explicit ray list: one lane per ray.
-template <bool WGSL, bool ANY, bool STATS, bool BOXES>
+template <bool WGSL, bool ANY, bool STATS, bool BOXES, bool TEX = false, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __restrict__ origins,
                                                     const float* __restrict__ dirs, uint32_t n,
                                                     uint2* __restrict__ out, unsigned long long* stats) {
@@ -441,7 +474,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __r
         HitRec h;
         n_rays = 1;
         const RayDir rd = make_ray_dir<WGSL>(ld3(dirs + 3 * (size_t)i), s.cell_size, s.px, s.pxy);
-        bool hit = trace_ray<WGSL, ANY, STATS, BOXES>(s, ld3(origins + 3 * (size_t)i), rd, h, ctr);
+        bool hit = trace_ray<WGSL, ANY, STATS, BOXES, TEX, WIDE>(s, ld3(origins + 3 * (size_t)i), rd, h, ctr);
         n_hit = hit ? 1 : 0;
         out[i] = hit ? make_uint2(h.id, __float_as_uint(h.t)) : make_uint2(MISS, 0u);
     }
@@ -449,7 +482,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __r
 }
 
 // One pixel, one lane: what the shader writes for its debug pixel (:695-709), geometry fields.
-template <bool WGSL>
+template <bool WGSL, bool WIDE = false>
 __global__ void k_debug_pixel(DevScene s, DevFrame f, uint32_t px, uint32_t py, float* __restrict__ info20) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
@@ -457,7 +490,7 @@ __global__ void k_debug_pixel(DevScene s, DevFrame f, uint32_t px, uint32_t py, 
     HitRec h;
     Counters ctr{0, 0, 0, 0};
     const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
-    const bool hit = trace_ray<WGSL, false, true, true>(s, o, rd, h, ctr);
+    const bool hit = trace_ray<WGSL, false, true, true, true, WIDE>(s, o, rd, h, ctr);
     for (int k = 0; k < 20; ++k) info20[k] = 0.0f;
     info20[0] = o.x, info20[1] = o.y, info20[2] = o.z;
     info20[3] = hit ? 1.0f : 0.0f;

@@ -15,7 +15,7 @@ namespace rt {
 template <int BODY, bool ANY>
 __device__ inline bool trace_ray_x(const DevScene& s, V3 o, const RayDir& rd, HitRec& out) {
     Counters ctr{0, 0, 0, 0};
-    return trace_ray<false, ANY, false, false, BODY>(s, o, rd, out, ctr);
+    return trace_ray<false, ANY, false, false, false, false, BODY>(s, o, rd, out, ctr);
 }
 
 __device__ unsigned long long g_wave_t[2 * 65536];  // s_memrealtime (100 MHz) at wave start / end

@@ -280,6 +280,17 @@ class TraceCore:
         m = np.ascontiguousarray(materials if materials is not None else np.zeros(0, MATERIAL_DTYPE), MATERIAL_DTYPE)
         self._ck(self._L.rt_set_materials(self._h, _ptr(m), len(m)))
 
+    def set_textures(self, textures):
+        """textures: sequence of (height, width, 4) uint8 arrays (TextureData of the loader, RGBA8 rows)."""
+        keep = [np.ascontiguousarray(t, np.uint8) for t in (textures or [])]
+        for t in keep:
+            if t.ndim != 3 or t.shape[2] != 4:
+                raise ValueError("a texture is a (height, width, 4) uint8 array")
+        arr = (_lib.RtTexture * max(1, len(keep)))()
+        for i, t in enumerate(keep):
+            arr[i].rgba8, arr[i].width, arr[i].height = t.ctypes.data, t.shape[1], t.shape[0]
+        self._ck(self._L.rt_set_textures(self._h, arr if keep else None, len(keep)))
+
     def render(self, cam, width, height, shard=None, max_bounces=8, shadows=False, debug_pixel=None, out=None):
         """The shader's picture: (n_pixels, 4) uint8 RGBA, row-major (tile-packed with a shard). `out` may be a
         torch CUDA uint8 tensor / device pointer to keep it on the GPU."""

@@ -335,6 +335,55 @@ def test_trace_parameter_variants(rt, ob, over):
     core.close()
 
 
+def test_grid_with_more_than_2_to_25_cells(core, ob, rt):
+    """Sizes at which library routines have been seen to stop working without an error: the per-cell sort of the
+    binning pass runs over the cells in batches from 2^24 cells on."""
+    rng = np.random.default_rng(5)
+    c = np.repeat(rng.uniform(-680, 680, (300, 1, 3)), 20, axis=0) + rng.normal(0, 3.0, (6000, 1, 3))  # 300 clusters
+    v = (c + rng.normal(0, 6.0, (6000, 3, 3))).astype(np.float32)
+    tris = ob.triangles_from_xyz9(v.reshape(-1, 9))
+    scene = setup_scene(core, ob, None, tris, cell_size=4.0, max_per_cell=3)
+    assert scene.grid.n_cells > 2 ** 25 + 2 ** 22
+    p = rt.default_params(max_objects_per_cell=3, max_dda_steps=1000)
+    core2 = rt.TraceCore(0, p)
+    setup_scene(core2, ob, None, tris, cell_size=4.0, max_per_cell=3)
+    w, h = 128, 72
+    cam = rt.Camera((0.0, 300.0, 2100.0), math.pi, -0.15).to_uniform(0.0, float(h))
+    gp, gs = core2.trace_primary(cam, w, h)
+    op, os_, _ = ob.trace_primary(scene, ocam(ob, cam), w, h, params=oparams(ob, p))
+    assert_hits_equal(gp, op, "primary")
+    assert_hits_equal(gs, os_, "shadow")
+    assert (gp["id"] != rt.RT_MISS).sum() > 20
+    core2.close()
+
+
+def test_reference_records_beyond_4_gib(core, ob, rt):
+    """More than 2^32 / 48 references: the trace kernels switch from buffer descriptors (32-bit byte offsets) to
+    plain pointers."""
+    rng = np.random.default_rng(6)
+    c = rng.uniform(-60, 60, (260, 1, 3))
+    v = (c + rng.normal(0, 45.0, (260, 3, 3))).astype(np.float32)
+    tris = ob.triangles_from_xyz9(v.reshape(-1, 9))
+    scene = setup_scene(core, ob, None, tris, cell_size=1.0)
+    assert (scene.grid.n_refs + 1) * 48 > 2 ** 32
+    w, h = 96, 54
+    cam = rt.Camera((30.0, 80.0, 420.0), math.pi, -0.15).to_uniform(0.0, float(h))
+    for stats in (False, True):
+        core.set_collect_stats(stats)
+        gp, gs = core.trace_primary(cam, w, h)
+        op, os_, st = ob.trace_primary(scene, ocam(ob, cam), w, h)
+        assert_hits_equal(gp, op, "primary")
+        assert_hits_equal(gs, os_, "shadow")
+        if stats:
+            got = core.stats()
+            assert {k: got[k] for k in st} == st
+    core.set_collect_stats(False)
+    o, d = ob.primary_rays(ocam(ob, cam), w, h)
+    assert_hits_equal(core.trace_rays(o, d, any_hit=True), ob.trace_rays(scene, o, d, any_hit=True)[0], "ray list")
+    img = core.render(cam, w, h, max_bounces=2)
+    assert np.array_equal(img, ob.render(scene, ocam(ob, cam), w, h, max_bounces=2)[0])
+
+
 def test_stats_equal_oracle_counts(core, ob, rt, car_xyz9):
     scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))
     cam = rt.Camera.for_scene("gltf").to_uniform(0.0, 135.0)

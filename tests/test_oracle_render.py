@@ -82,7 +82,8 @@ def test_bounces_debug_pixel_grid_overlay_and_shards(ob):
 
 def alpha_materials(ob):
     """0 opaque, 1 MASK below its cutoff (invisible), 2 MASK above it, 3 BLEND nearly transparent (invisible),
-    4 MASK below the cutoff but textured (cannot be judged without the texture: stays visible)."""
+    4 MASK, textured, factor alpha below the cutoff: with no texture array the renderer binds a white dummy, so
+    alpha = 1 * 0.1 and the material is invisible too; with textures it depends on the texel."""
     m = np.zeros(5, ob.MATERIAL_DTYPE)
     m["texture_index"] = m["normal_texture_index"] = m["emissive_texture_index"] = -1
     m["roughness"] = 1.0
@@ -104,10 +105,14 @@ def test_alpha_rules_make_triangles_invisible(ob, car_xyz9):
     p, s, _ = ob.trace_primary(scene, cam, w, h)
     p0, _, _ = ob.trace_primary(plain, cam, w, h)
     hit = p["id"] != ob.MISS
-    assert not np.isin(p["id"][hit] % 6, (1, 3)).any() and np.isin(p0["id"][p0["id"] != ob.MISS] % 6, (1, 3)).any()
+    assert not np.isin(p["id"][hit] % 6, (1, 3, 4)).any() and np.isin(p0["id"][p0["id"] != ob.MISS] % 6, (1, 3, 4)).any()
     sh = s["id"] != ob.MISS
-    assert not np.isin(s["id"][sh] % 6, (1, 3)).any()
-    assert np.isin(p["id"][hit] % 6, (4,)).any()  # the textured one is still there
+    assert not np.isin(s["id"][sh] % 6, (1, 3, 4)).any()
+    # an opaque texel (alpha 255 * 0.1 is still below the cutoff; raise the factor) brings material 4 back
+    mats2 = mats.copy()
+    mats2["base_color"][4][3] = 0.9
+    p2, _, _ = ob.trace_primary(ob.Scene(None, tris, materials=mats2, textures=[np.full((2, 2, 4), 255, np.uint8)]), cam, w, h)
+    assert np.isin(p2["id"][p2["id"] != ob.MISS] % 6, (4,)).any()
     # traversal agrees with testing every triangle
     o, d = ob.primary_rays(cam, w, h)
     brute = ob.trace_rays_bruteforce(scene, o, d)

@@ -41,6 +41,7 @@ extern "C" {
                          out: *mut RtHit, any_hit: c_int) -> c_int;
     pub fn rt_set_stream(ctx: *mut RtCtx, hip_stream: *mut c_void) -> c_int;
     pub fn rt_set_materials(ctx: *mut RtCtx, materials: *const c_void, n: u32) -> c_int;
+    pub fn rt_set_textures(ctx: *mut RtCtx, textures: *const RtTexture, n: u32) -> c_int;
     pub fn rt_set_skin(ctx: *mut RtCtx, positions: *const f32, joints: *const u16, weights: *const f32, n_vertices: u32,
                        tri_indices: *const u32, n_triangles: u32) -> c_int;
     pub fn rt_skin_vertices(ctx: *mut RtCtx, joint_matrices: *const f32, n_joints: u32) -> c_int;
@@ -92,7 +93,25 @@ impl TraceCore {
     }
 }
 
+/// `rt_texture`: one `TextureData` of the loader (src/loaders/gltf_triangles.rs:15-19), borrowed for the call.
+#[repr(C)]
+pub struct RtTexture {
+    pub rgba8: *const u8,
+    pub width: u32,
+    pub height: u32,
+}
+
 impl TraceCore {
+    /// `Vec<TextureData>` as `(width, height, RGBA8 bytes)`: what the renderer turns into its texture array
+    /// (src/renderer.rs:158-259).
+    pub fn set_textures(&mut self, textures: &[(u32, u32, &[u8])]) -> Result<(), String> {
+        let recs: Vec<RtTexture> = textures.iter().map(|(w, h, data)| {
+            assert!(data.len() >= (*w as usize) * (*h as usize) * 4);
+            RtTexture { rgba8: data.as_ptr(), width: *w, height: *h }
+        }).collect();
+        self.check(unsafe { rt_set_textures(self.ctx, if recs.is_empty() { std::ptr::null() } else { recs.as_ptr() }, recs.len() as u32) })
+    }
+
     /// `Vec<MaterialData>` bytes (src/types.rs:248-261), the renderer's "Materials" buffer.
     pub fn set_materials(&mut self, materials: &[u8]) -> Result<(), String> {
         self.check(unsafe { rt_set_materials(self.ctx, materials.as_ptr() as *const c_void, (materials.len() / 64) as u32) })

@@ -98,6 +98,11 @@ public:
         check(rt_set_materials(ctx_, materials.data(), (uint32_t)materials.size()));
     }
 
+    // The texture array (src/renderer.rs:158-259) from the loader's TextureData records.
+    void set_textures(const std::vector<rt_texture>& textures) {
+        check(rt_set_textures(ctx_, textures.empty() ? nullptr : textures.data(), (uint32_t)textures.size()));
+    }
+
     GridMetadata grid_metadata() const {
         GridMetadata m;
         check(rt_get_grid(ctx_, &m, nullptr, nullptr));

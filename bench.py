@@ -11,7 +11,11 @@ flight): a frame's last waves - a few pixel blocks over the model's densest cell
 each - then overlap the next frame's bulk instead of leaving the GPU idle. At N > 1
 the SAME frame is cut into 64x64 tiles dealt round-robin to the ranks, each rank shades its tiles (same
 primary + shadow rays) and the RGBA8 framebuffer is gathered on rank 0 by RCCL (total work fixed: strong
-scaling; 4 bytes per pixel cross the links instead of 16 for hit records). Prints one JSON line on rank 0.
+scaling; 4 bytes per pixel cross the links instead of 16 for hit records). A rank's share of one 1080p frame is
+only ~10 us of GPU work, far less than one launch + one collective cost on the host, so at N > 1 the steps run as
+groups of GROUP consecutive frames: one launch renders the rank's tiles of the whole group, one gather moves them,
+one launch assembles them (a renderer running a camera path ahead of display); every frame is still traced,
+gathered and assembled in full inside the timed region. Prints one JSON line on rank 0.
 
 The frame's work (cells visited, candidates tested, rays) is counted by the kernel's own counters in an
 untimed launch. The CPU oracle is used for one thing only, outside the timed region: the `cpu_baseline`
@@ -32,11 +36,12 @@ import torch  # noqa: E402
 
 WIDTH, HEIGHT = 1920, 1080
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-TILE = 64
+TILE = 32
 FRAMES_IN_FLIGHT = 2
 # At N > 1 a rank owns 1/N of the tiles but its slowest pixel block still is a ~100 us dependent chain, and every
 # frame also spends time on the links: more frames have to be in flight to keep the GPUs busy.
-FRAMES_IN_FLIGHT_MULTI = 4
+GROUP = 16            # frames per launch / gather / assemble at N > 1
+GROUPS_IN_FLIGHT = 3
 
 
 def algorithmic_bytes(stats):
@@ -165,12 +170,20 @@ def main():
     else:
         # the framebuffer that travels is the shaded RGBA8 picture; one bounce = the same primary + shadow rays
         sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
-                                   frames_in_flight=FRAMES_IN_FLIGHT_MULTI, max_bounces=1)
+                                   frames_in_flight=1, max_bounces=1)
+        sh.enable_groups(GROUP, GROUPS_IN_FLIGHT)
+        pending = []
 
         def step():
-            sh.trace(cam)
+            pending.append(cam)
+            if len(pending) == GROUP:
+                sh.trace_group(pending)
+                pending.clear()
 
         def sync():
+            if pending:  # a last, partial group
+                sh.trace_group(pending)
+                pending.clear()
             sh.synchronize()
 
     for _ in range(args.warmup):
@@ -231,7 +244,8 @@ def main():
                        "width": WIDTH, "height": HEIGHT, "rays_per_frame": rays_per_frame,
                        "primary_hits": stats["primary_hits"], "grid": list(meta.fine_dims), "cell_size": 16.0,
                        "cells": n_cells, "cell_refs": n_refs,
-                       "frames_in_flight": FRAMES_IN_FLIGHT if world == 1 else FRAMES_IN_FLIGHT_MULTI,
+                       "frames_in_flight": FRAMES_IN_FLIGHT if world == 1 else GROUP * GROUPS_IN_FLIGHT,
+                       "frames_per_launch_and_gather": 1 if world == 1 else GROUP,
                        "output": "rt_hit records, 16 B per pixel, resident in HBM" if world == 1 else
                                  "shaded RGBA8 picture (ambient + diffuse with the shadow-ray term), 4 B per pixel, gathered on rank 0",
                        "parallelism": "single GPU" if world == 1 else f"{TILE}x{TILE} tiles round-robin over {world} GPUs, RCCL gather to rank 0"},

@@ -274,9 +274,24 @@ int rt_set_textures(rt_ctx* ctx, const rt_texture* textures, uint32_t n);
 int rt_render(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height, const rt_shard* shard,
               const rt_render_opts* opts, uint8_t* out_rgba8);
 
+/* rt_render for up to 16 consecutive frames of a camera path in ONE launch: cameras[j] renders into
+ * out_rgba8 + j * (bytes of one frame's output), everything else as in rt_render. The reference dispatches one
+ * frame at a time (src/renderer.rs:857-868); a multi-GPU caller that owns only 1/N of every frame's tiles uses
+ * this so that the few expensive pixel blocks of one frame (one long dependent chain each) overlap the bulk of
+ * the other frames instead of leaving its GPU idle, and so that one framebuffer gather carries many frames. */
+int rt_render_frames(rt_ctx* ctx, const CameraUniform* cameras, uint32_t n_frames, uint32_t width, uint32_t height,
+                     const rt_shard* shard, const rt_render_opts* opts, uint8_t* out_rgba8);
+
 /* rt_assemble_tiles for rt_render's 4-byte pixels. No reference counterpart. */
 int rt_assemble_tiles_rgba8(rt_ctx* ctx, const uint8_t* gathered, uint32_t width, uint32_t height,
                             uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, uint8_t* image);
+
+/* The same for n_frames frames gathered together (rt_render_frames on every rank): frame j of rank r starts at
+ * pixel r*rank_stride + j*frame_stride of gathered; images receives n_frames row-major pictures back to back.
+ * No reference counterpart. */
+int rt_assemble_frames_rgba8(rt_ctx* ctx, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+                             uint32_t tile_h, uint32_t n_ranks, uint32_t n_frames, size_t rank_stride,
+                             size_t frame_stride, uint8_t* images);
 
 /* Counters of the most recent trace call made with params.collect_stats = 1. */
 int rt_get_stats(rt_ctx* ctx, rt_stats* stats);

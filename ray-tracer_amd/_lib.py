@@ -121,6 +121,8 @@ PROTOTYPES = {
     "rt_skin_vertices": (_I, [_VP, _VP, _U32]),
     "rt_read_vertices": (_I, [_VP, _VP]),
     "rt_assemble_tiles_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
+    "rt_assemble_frames_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, C.c_size_t, C.c_size_t, _VP]),
+    "rt_render_frames": (_I, [_VP, _VP, _U32, _U32, _U32, C.POINTER(RtShard), C.POINTER(RtRenderOpts), _VP]),
     "rt_default_render_opts": (None, [C.POINTER(RtRenderOpts)]),
     "rt_set_materials": (_I, [_VP, _VP, _U32]),
     "rt_set_textures": (_I, [_VP, _VP, _U32]),

@@ -206,10 +206,12 @@ __global__ void k_tri_pairs_watertight(const float* __restrict__ o, const float*
 
 template <class PIXEL>
 __global__ void k_assemble(const PIXEL* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w,
-                           uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks, size_t per_rank,
+                           uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks, size_t per_rank, size_t frame_stride,
                            PIXEL* __restrict__ image) {
     uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= width || y >= height) return;
+    gathered += (size_t)blockIdx.z * frame_stride;
+    image += (size_t)blockIdx.z * width * height;
     uint32_t tile = (y / tile_h) * tiles_x + (x / tile_w);
     uint32_t rank = tile % n_ranks, lt = tile / n_ranks;
     size_t src = (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h + (size_t)(y % tile_h) * tile_w + (x % tile_w);
@@ -296,18 +298,24 @@ DevFrame make_frame(const rt_ctx* c, const CameraUniform* cam, uint32_t w, uint3
     return f;
 }
 
-int update_box_frame(rt_ctx* c, const CameraUniform* cam) {
+// Per-frame box records for n consecutive frames (frame j at record 4 * nb * j).
+int update_box_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n) {
     if (c->grid_nb == 0) return RT_OK;
-    if (!cam) return fail(c, RT_ERR_INVALID, "camera is required when the scene has boxes (LOD cull, box motion)");
-    RT_HIP(c, c->box_frame.reserve((size_t)c->nb * 4 * sizeof(float4)));
+    if (!cams) return fail(c, RT_ERR_INVALID, "camera is required when the scene has boxes (LOD cull, box motion)");
+    RT_HIP(c, c->box_frame.reserve((size_t)c->nb * 4 * sizeof(float4) * n));
     c->scratch_busy = true;
-    float t_lerp = (sinf(cam->time * 2.0f) + 1.0f) * 0.5f;  // raytracer_unified.wgsl:201,449
-    hipLaunchKernelGGL(k_box_frame, dim3((c->nb + 255) / 256), dim3(256), 0, c->stream, c->boxes.as<BoxData>(), c->nb,
-                       t_lerp, ld3(cam->position), cam->lod_factor, cam->min_pixel_size, c->params.lod_cull,
-                       c->box_frame.as<float4>());
+    for (uint32_t j = 0; j < n; ++j) {
+        const CameraUniform* cam = cams + j;
+        float t_lerp = (sinf(cam->time * 2.0f) + 1.0f) * 0.5f;  // raytracer_unified.wgsl:201,449
+        hipLaunchKernelGGL(k_box_frame, dim3((c->nb + 255) / 256), dim3(256), 0, c->stream, c->boxes.as<BoxData>(), c->nb,
+                           t_lerp, ld3(cam->position), cam->lod_factor, cam->min_pixel_size, c->params.lod_cull,
+                           c->box_frame.as<float4>() + (size_t)c->nb * 4 * j);
+    }
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
+
+int update_box_frame(rt_ctx* c, const CameraUniform* cam) { return update_box_frames(c, cam, 1); }
 
 ShardMap make_shard(uint32_t w, uint32_t h, const rt_shard* sh) {
     ShardMap m;
@@ -871,7 +879,8 @@ extern "C" int rt_trace_rays(rt_ctx* c, const CameraUniform* cam, const float* o
 
 template <class PIXEL>
 static int assemble_tiles(rt_ctx* c, const void* gathered, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
-                          uint32_t n_ranks, size_t rank_stride, void* image, const char* who) {
+                          uint32_t n_ranks, size_t rank_stride, void* image, const char* who, uint32_t n_frames = 1,
+                          size_t frame_stride = 0) {
     if (int r = use(c)) return r;
     if (!gathered || !image || !width || !height || !tile_w || !tile_h || !n_ranks)
         return fail(c, RT_ERR_INVALID, "%s: NULL or zero argument", who);
@@ -881,9 +890,13 @@ static int assemble_tiles(rt_ctx* c, const void* gathered, uint32_t width, uint3
     const size_t min_stride = (size_t)((tiles_x * tiles_y + n_ranks - 1) / n_ranks) * tile_w * tile_h;
     const size_t per_rank = rank_stride ? rank_stride : min_stride;
     if (per_rank < min_stride) return fail(c, RT_ERR_INVALID, "%s: rank_stride smaller than one rank's block", who);
-    hipLaunchKernelGGL(k_assemble<PIXEL>, dim3((width + 255) / 256, height), dim3(256), 0, c->stream,
+    if (n_frames == 0) return RT_OK;
+    if (n_frames > 65535u) return fail(c, RT_ERR_LIMIT, "%s: more than 65535 frames", who);
+    if (n_frames > 1 && (frame_stride < min_stride || per_rank < (size_t)n_frames * min_stride))
+        return fail(c, RT_ERR_INVALID, "%s: frame_stride / rank_stride smaller than the frames they hold", who);
+    hipLaunchKernelGGL(k_assemble<PIXEL>, dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream,
                        reinterpret_cast<const PIXEL*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks, per_rank,
-                       reinterpret_cast<PIXEL*>(image));
+                       frame_stride, reinterpret_cast<PIXEL*>(image));
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -897,6 +910,14 @@ extern "C" int rt_assemble_tiles_rgba8(rt_ctx* c, const uint8_t* gathered, uint3
                                        uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, uint8_t* image) {
     return assemble_tiles<uint32_t>(c, gathered, width, height, tile_w, tile_h, n_ranks, rank_stride, image,
                                     "rt_assemble_tiles_rgba8");
+}
+
+extern "C" int rt_assemble_frames_rgba8(rt_ctx* c, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+                                        uint32_t tile_h, uint32_t n_ranks, uint32_t n_frames, size_t rank_stride,
+                                        size_t frame_stride, uint8_t* images) {
+    if (n_frames > 1 && !rank_stride) return fail(c, RT_ERR_INVALID, "rt_assemble_frames_rgba8: rank_stride is required");
+    return assemble_tiles<uint32_t>(c, gathered, width, height, tile_w, tile_h, n_ranks, rank_stride, images,
+                                    "rt_assemble_frames_rgba8", n_frames, frame_stride);
 }
 
 // ================================================================== skinning
@@ -1024,19 +1045,22 @@ extern "C" void rt_default_render_opts(rt_render_opts* o) {
     o->max_bounces = 8;  // MAX_BOUNCES, raytracer_unified.wgsl:656
 }
 
-extern "C" int rt_render(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height, const rt_shard* shard,
-                         const rt_render_opts* opts, uint8_t* out_rgba8) {
+extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n_frames, uint32_t width, uint32_t height,
+                                const rt_shard* shard, const rt_render_opts* opts, uint8_t* out_rgba8) {
     if (int r = use(c)) return r;
     if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_render: no grid (call rt_build_grid or rt_set_grid_*)");
-    if (!cam || !out_rgba8) return fail(c, RT_ERR_INVALID, "rt_render: NULL camera or output");
+    if (!cams || !out_rgba8) return fail(c, RT_ERR_INVALID, "rt_render: NULL camera or output");
     if (!width || !height) return fail(c, RT_ERR_INVALID, "rt_render: empty frame");
+    if (n_frames == 0) return RT_OK;
+    if (n_frames > MAX_FRAMES_PER_LAUNCH)
+        return fail(c, RT_ERR_LIMIT, "rt_render_frames: %u frames in one call (max %u)", n_frames, MAX_FRAMES_PER_LAUNCH);
     if (shard && (!shard->tile_w || !shard->tile_h || !shard->stride))
         return fail(c, RT_ERR_INVALID, "rt_render: shard tile size and stride must be non-zero");
     rt_render_opts o;
     rt_default_render_opts(&o);
     if (opts) o = *opts;
     const ShardMap m = make_shard(width, height, shard);
-    const size_t n_out = (size_t)m.n_local * m.tile_w * m.tile_h;
+    const size_t n_frame = (size_t)m.n_local * m.tile_w * m.tile_h, n_out = n_frame * n_frames;
     if (n_out == 0) return RT_OK;
     const uint64_t blocks = (uint64_t)m.n_local * ((m.sub_x + 1) / 2) * ((m.sub_y + 1) / 2);
     if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "rt_render: frame too large");
@@ -1046,12 +1070,17 @@ extern "C" int rt_render(rt_ctx* c, const CameraUniform* cam, uint32_t width, ui
         RT_HIP(c, c->out_p.reserve(n_out * sizeof(uint32_t)));
         out = c->out_p.as<uint32_t>();
     }
-    if (int r = update_box_frame(c, cam)) return r;
+    if (int r = update_box_frames(c, cams, n_frames)) return r;
     const bool stats = c->params.collect_stats != 0;
     if (stats)
         if (int r = zero_stats(c)) return r;
     const DevScene s = make_scene(c);
-    const DevFrame f = make_frame(c, cam, width, height);
+    DevFrames fs;
+    memset(&fs, 0, sizeof(fs));
+    for (uint32_t j = 0; j < n_frames; ++j) {
+        fs.f[j] = make_frame(c, cams + j, width, height);
+        fs.show_grid[j] = cams[j].show_grid;
+    }
     DevShade sh;
     memset(&sh, 0, sizeof(sh));
     sh.boxes = c->boxes.as<float4>();
@@ -1063,20 +1092,21 @@ extern "C" int rt_render(rt_ctx* c, const CameraUniform* cam, uint32_t width, ui
     sh.debug_enabled = o.debug_enabled;
     sh.debug_x = o.debug_pixel[0];
     sh.debug_y = o.debug_pixel[1];
-    sh.show_grid = cam->show_grid;
+    sh.box_frame_stride = c->nb * 4;
+    sh.frame_pixels = n_frame;
     unsigned long long* st = stats ? c->stats.as<unsigned long long>() : nullptr;
-    const dim3 grid((uint32_t)blocks);
+    const dim3 grid((uint32_t)blocks, n_frames);
     const bool wgsl = c->params.wgsl_compat != 0, has_boxes = s.nb != 0;
     if (wide_grid(s)) {
-        if (wgsl) hipLaunchKernelGGL((k_render<true, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
-        else hipLaunchKernelGGL((k_render<false, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+        if (wgsl) hipLaunchKernelGGL((k_render<true, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        else hipLaunchKernelGGL((k_render<false, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
     } else if (c->tex_mode != 0) {  // materials name textures: the general kernel with the material path
-        if (wgsl) hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
-        else hipLaunchKernelGGL((k_render<false, true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
-    } else if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
-    else if (wgsl) hipLaunchKernelGGL((k_render<true, false>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
-    else if (has_boxes) hipLaunchKernelGGL((k_render<false, true>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
-    else hipLaunchKernelGGL((k_render<false, false>), grid, dim3(256), 0, c->stream, s, f, m, sh, out, st);
+        if (wgsl) hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        else hipLaunchKernelGGL((k_render<false, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+    } else if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+    else if (wgsl) hipLaunchKernelGGL((k_render<true, false>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+    else if (has_boxes) hipLaunchKernelGGL((k_render<false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+    else hipLaunchKernelGGL((k_render<false, false>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
     RT_HIP(c, hipGetLastError());
     if (host_out) RT_HIP(c, hipMemcpyAsync(out_rgba8, out, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (stats) {
@@ -1085,6 +1115,11 @@ extern "C" int rt_render(rt_ctx* c, const CameraUniform* cam, uint32_t width, ui
         RT_HIP(c, hipStreamSynchronize(c->stream));
     }
     return RT_OK;
+}
+
+extern "C" int rt_render(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height, const rt_shard* shard,
+                         const rt_render_opts* opts, uint8_t* out_rgba8) {
+    return rt_render_frames(c, cam, 1, width, height, shard, opts, out_rgba8);
 }
 
 extern "C" int rt_debug_pixel(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height, uint32_t px,

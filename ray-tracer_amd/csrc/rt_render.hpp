@@ -24,7 +24,16 @@ struct DevShade {
     uint32_t max_bounces;
     uint32_t shadows;         // 1: a hit whose shadow ray is occluded gets no diffuse light (not in the shader)
     uint32_t debug_enabled, debug_x, debug_y;
-    float show_grid;
+    uint32_t box_frame_stride;  // float4 records between the per-frame box records of consecutive frames
+    size_t frame_pixels;        // output records per frame
+};
+
+// Frames of one launch (blockIdx.y picks one): consecutive frames of a camera path rendered together, so that the
+// long dependent chains of the few expensive pixel blocks of one frame overlap the bulk of the others.
+constexpr uint32_t MAX_FRAMES_PER_LAUNCH = 16;
+struct DevFrames {
+    DevFrame f[MAX_FRAMES_PER_LAUNCH];
+    float show_grid[MAX_FRAMES_PER_LAUNCH];
 };
 
 __device__ inline uint32_t unorm8(float c) {
@@ -41,9 +50,16 @@ __device__ inline bool near_grid_boundary(const DevScene& s, V3 pos, float thres
     return dx < threshold || dy < threshold || dz < threshold;
 }
 
+#ifndef RT_RENDER_WAVES
+#define RT_RENDER_WAVES 1
+#endif
 template <bool WGSL, bool BOXES, bool TEX = false, bool WIDE = false>
-__global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(DevScene s, DevFrames fs, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
                                                 unsigned long long* stats) {
+    const DevFrame& f = fs.f[blockIdx.y];
+    const float show_grid = fs.show_grid[blockIdx.y];
+    s.box_frame += (size_t)blockIdx.y * sh.box_frame_stride;
+    out += (size_t)blockIdx.y * sh.frame_pixels;
     const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
     const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;
     const uint32_t blk_per_tile = blk_x * blk_y;
@@ -58,7 +74,8 @@ __global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap
 
     uint32_t rgba = 0;
     Counters ctr{0, 0, 0, 0};
-    unsigned long long n_rays = 0, n_ph = 0, n_sr = 0, n_sh = 0;
+    // rays, primary hits, shadow rays, shadow hits of this pixel: at most 8 bounces, so a byte each in one register
+    uint32_t counts = 0;
     if (live) {
         V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         V3 d = primary_dir(f, px, py);
@@ -68,40 +85,31 @@ __global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap
         for (uint32_t bounce = 0; bounce < sh.max_bounces; ++bounce) {
             const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
             HitRec h;
-            n_rays++;
+            counts += 1u;
             if (!trace_ray<WGSL, false, false, BOXES, TEX, WIDE>(s, o, rd, h, ctr)) {
                 // sky (:591-596)
                 const float t = (d.y + 1.0f) * 0.5f;
                 acc = acc + mix(v3(0.3f, 0.5f, 0.7f), v3(0.5f, 0.7f, 1.0f), t) * mult;
                 break;
             }
-            if (bounce == 0) n_ph++;
+            if (bounce == 0) counts += 1u << 8;
+            // Only what the shadow ray needs is evaluated before it (position, normal); colour, emissive and
+            // reflectivity are fetched afterwards, so they do not occupy registers during the second traversal.
             const V3 pos = o + d * h.t;
             V3 n = hit_normal(s, h, pos);
-            V3 color = v3(0.7f, 0.7f, 0.7f), emissive = v3(0.0f, 0.0f, 0.0f);
-            float refl = 0.0f;
-            if (BOXES && h.ref == MISS) {
-                const float4 c = sh.boxes[6 * h.id + 2];
-                color = v3(c.x, c.y, c.z);
-                refl = c.w;
-            } else {
-                const uint32_t mat = sh.tri_mat[h.id - s.nb];
-                if (mat < sh.n_materials) {
-                    const float4 m0 = sh.materials[4 * mat], m1 = sh.materials[4 * mat + 1], m2 = sh.materials[4 * mat + 2];
-                    color = v3(m0.x, m0.y, m0.z);
-                    emissive = v3(m1.x, m1.y, m1.z);
-                    refl = m2.x;  // metallic (:361)
-                    if (TEX) {
-                        const float4 c0 = s.refs[3 * (size_t)h.ref], c1 = s.refs[3 * (size_t)h.ref + 1],
-                                     c2 = s.refs[3 * (size_t)h.ref + 2];
-                        float bu, bv;
-                        hit_barycentrics(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z), v3(c2.x, c2.y, c2.z), bu, bv);
-                        const F2 uv = hit_uv(s.tex, h.id - s.nb, bu, bv);
-                        const float4 bc = base_color(s.tex, mat, uv);
-                        color = v3(bc.x, bc.y, bc.z);
-                        n = mapped_normal(s.tex, mat, uv, n);
-                        emissive = emissive_color(s.tex, mat, uv);
-                    }
+            const bool is_box = BOXES && h.ref == MISS;
+            uint32_t mat = MISS;
+            F2 uv{0.0f, 0.0f};
+            if (!is_box) {
+                mat = sh.tri_mat[h.id - s.nb];
+                if (mat >= sh.n_materials) mat = MISS;
+                if (TEX && mat != MISS) {
+                    const float4 c0 = s.refs[3 * (size_t)h.ref], c1 = s.refs[3 * (size_t)h.ref + 1],
+                                 c2 = s.refs[3 * (size_t)h.ref + 2];
+                    float bu, bv;
+                    hit_barycentrics(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z), v3(c2.x, c2.y, c2.z), bu, bv);
+                    uv = hit_uv(s.tex, h.id - s.nb, bu, bv);
+                    n = mapped_normal(s.tex, mat, uv, n);
                 }
             }
             // lighting (:598-603)
@@ -110,15 +118,31 @@ __global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap
                 V3 nf = n;
                 if (dot(nf, d) > 0.0f) nf = neg(nf);
                 HitRec oh;
-                n_rays++;
-                n_sr++;
+                counts += 0x10001u;
                 if (trace_ray<WGSL, true, false, BOXES, TEX, WIDE>(s, pos + nf * f.shadow_offset, f.shadow, oh, ctr)) {
-                    n_sh++;
+                    counts += 1u << 24;
                     diffuse = 0.0f;
                 }
             }
+            V3 color = v3(0.7f, 0.7f, 0.7f), emissive = v3(0.0f, 0.0f, 0.0f);
+            float refl = 0.0f;
+            if (is_box) {
+                const float4 c = sh.boxes[6 * h.id + 2];
+                color = v3(c.x, c.y, c.z);
+                refl = c.w;
+            } else if (mat != MISS) {
+                const float4 m0 = sh.materials[4 * mat], m1 = sh.materials[4 * mat + 1], m2 = sh.materials[4 * mat + 2];
+                color = v3(m0.x, m0.y, m0.z);
+                emissive = v3(m1.x, m1.y, m1.z);
+                refl = m2.x;  // metallic (:361)
+                if (TEX) {
+                    const float4 bc = base_color(s.tex, mat, uv);
+                    color = v3(bc.x, bc.y, bc.z);
+                    emissive = emissive_color(s.tex, mat, uv);
+                }
+            }
             V3 lit = color * (0.3f + diffuse * 0.7f) + emissive;
-            if (sh.show_grid > 0.5f && near_grid_boundary(s, pos, 0.02f)) lit = mix(lit, v3(0.0f, 1.0f, 0.0f), 0.6f);
+            if (show_grid > 0.5f && near_grid_boundary(s, pos, 0.02f)) lit = mix(lit, v3(0.0f, 1.0f, 0.0f), 0.6f);
             // bounce loop (:670-688)
             acc = acc + (lit * (1.0f - refl)) * mult;
             if (refl < 0.01f) break;
@@ -137,7 +161,7 @@ __global__ __launch_bounds__(256) void k_render(DevScene s, DevFrame f, ShardMap
         rgba = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xFF000000u;
     }
     if (in_tile) out[(size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx] = rgba;
-    if (stats) flush_stats(stats, n_rays, n_ph, n_sr, n_sh, ctr);
+    if (stats) flush_stats(stats, counts & 255u, (counts >> 8) & 255u, (counts >> 16) & 255u, counts >> 24, ctr);
 }
 
 }  // namespace rt

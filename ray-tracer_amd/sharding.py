@@ -18,6 +18,11 @@ frame shards without any data-path exchange until the end:
 
 No step synchronises the host. Frames can be kept in flight (separate streams and buffers per frame), which
 overlaps a frame's gather, and the long tail of its trace kernel, with the next frame's tracing.
+For throughput (a camera path rendered ahead of display) frames travel in GROUPS: `trace_group` renders this rank's
+tiles of up to 16 consecutive frames in one launch (rt_render_frames), gathers them in one collective and assembles
+them in one launch, so launch, collective and host costs are paid once per group instead of once per frame, and
+the expensive pixel blocks of one frame overlap the other frames of the group. Groups are kept in flight like
+frames.
 The tracer is passed in (`core`): the product passes a ray_tracer_amd.TraceCore; the CPU tests pass
 a stand-in so the sharding logic runs under gloo without a GPU.
 """
@@ -83,6 +88,19 @@ class _Slot:
                 self.image = torch.empty((s.blocks, s.height * s.width, 2), dtype=torch.int32, device=device)
 
 
+class _GroupSlot:
+    """Buffers and stream of one group of frames in flight: [frame][record][r, g, b, a] per rank."""
+
+    def __init__(self, sharder, device):
+        s = sharder
+        self.stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
+        self.local = torch.zeros((s.group, s.per_rank, 4), dtype=torch.uint8, device=device)
+        self.packed = self.images = None
+        if s.rank == 0:
+            self.packed = torch.empty((s.world, s.group, s.per_rank, 4), dtype=torch.uint8, device=device)
+            self.images = torch.empty((s.group, s.height * s.width, 4), dtype=torch.uint8, device=device)
+
+
 class FrameSharder:
     """Traces this rank's tiles of a frame and gathers the frame on rank 0.
 
@@ -110,6 +128,7 @@ class FrameSharder:
         # only waits for work queued on torch's current stream, and makes that stream wait for its completion.
         self.slots = [_Slot(self, device) for _ in range(max(1, frames_in_flight))]
         self.frame = 0
+        self.group, self.gslots, self.group_no = 0, [], 0
         self.local, self.packed, self.image = self.slots[0].local, self.slots[0].packed, self.slots[0].image
 
     def _local(self, cam, slot):
@@ -137,9 +156,47 @@ class FrameSharder:
         return self._trace(cam, slot)
 
     def synchronize(self):
-        for slot in self.slots:
+        for slot in self.slots + self.gslots:
             if slot.stream is not None:
                 slot.stream.synchronize()
+
+    # ---- groups of frames ("rgba" mode)
+    def enable_groups(self, group=8, groups_in_flight=2):
+        """Allocates buffers for `groups_in_flight` groups of up to `group` frames each."""
+        if self.mode != "rgba":
+            raise ValueError("frame groups carry the shaded picture: mode must be 'rgba'")
+        if not 1 <= group <= 16:
+            raise ValueError("a group holds 1 to 16 frames (one rt_render_frames launch)")
+        self.group = group
+        self.gslots = [_GroupSlot(self, self.device) for _ in range(max(1, groups_in_flight))]
+
+    def trace_group(self, cams):
+        """len(cams) <= group consecutive frames. On rank 0 returns the (len(cams), height*width, 4) uint8 pictures
+        (valid until `groups_in_flight` further groups have been started); None on the other ranks."""
+        if not self.gslots:
+            self.enable_groups()
+        g = len(cams)
+        if not 1 <= g <= self.group:
+            raise ValueError(f"a group holds 1 to {self.group} frames")
+        slot = self.gslots[self.group_no % len(self.gslots)]
+        self.group_no += 1
+        if slot.stream is not None:
+            self.core.set_stream(slot.stream.cuda_stream)
+            with torch.cuda.stream(slot.stream):
+                return self._trace_group(cams, g, slot)
+        return self._trace_group(cams, g, slot)
+
+    def _trace_group(self, cams, g, slot):
+        self.core.render_frames(cams, self.width, self.height, shard=self.shard, max_bounces=self.max_bounces,
+                                shadows=self.shadow, out=slot.local[:g])
+        if self.world > 1:
+            dist.gather(slot.local[:g], [slot.packed[r, :g] for r in range(self.world)] if self.rank == 0 else None, dst=0)
+        if self.rank != 0:
+            return None
+        src = slot.packed if self.world > 1 else slot.local.unsqueeze(0)
+        self.core.assemble_frames_rgba8(src, self.width, self.height, self.tile_w, self.tile_h, self.world, g,
+                                        self.group * self.per_rank, self.per_rank, slot.images[:g])
+        return slot.images[:g]
 
     def _trace(self, cam, slot):
         self._local(cam, slot)

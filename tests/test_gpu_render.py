@@ -176,6 +176,59 @@ def test_frame_sharder_on_the_gpu_single_rank(core, ob, rt, car_xyz9):
         assert np.array_equal(gs["id"], ws["id"]) and np.array_equal(gs["t"].view(np.uint32), ws["t"].view(np.uint32))
 
 
+def test_render_frames_equals_frame_by_frame(core, ob, rt, car_xyz9):
+    """Several frames of a camera path in one launch: every frame byte for byte what rt_render gives for it, and the
+    oracle's picture; boxes move and are LOD-culled per frame (time and position differ between the frames)."""
+    from render_scenes import demo_boxes
+    import torch
+    boxes = demo_boxes(ob)
+    tris = ob.triangles_from_xyz9(car_xyz9[:600] * np.float32(0.1))
+    core.set_scene(boxes, tris)
+    core.set_materials(None)
+    core.build_grid(cell_size=4.0)
+    scene = ob.Scene(boxes, tris, cell_size=4.0)
+    w, h = 200, 120
+    cams = [rt.Camera((4.0 + 3 * j, 12.0 + j, 40.0 - 2 * j), math.pi + 0.05 * j, -0.25).to_uniform(0.3 * j, float(h), show_grid=(j == 2))
+            for j in range(16)]
+    got = core.render_frames(cams, w, h, max_bounces=3, shadows=True)
+    assert got.shape == (16, w * h, 4)
+    for j, cam in enumerate(cams):
+        assert np.array_equal(got[j], core.render(cam, w, h, max_bounces=3, shadows=True)), f"frame {j} vs rt_render"
+    for j in (0, 2, 9, 15):
+        assert np.array_equal(got[j], ob.render(scene, ocam(ob, cams[j]), w, h, max_bounces=3, shadows=True)[0]), f"frame {j} vs oracle"
+    # tile-packed and on the device
+    shard = rt.RtShard(64, 32, 1, 3)
+    n = rt.shard_pixels(w, h, shard)
+    dev = torch.zeros((5, n, 4), dtype=torch.uint8, device="cuda")
+    core.render_frames(cams[3:8], w, h, shard=shard, out=dev)
+    core.sync()
+    for j in range(5):
+        assert np.array_equal(dev[j].cpu().numpy(), core.render(cams[3 + j], w, h, shard=shard)), f"sharded frame {j}"
+    with pytest.raises(rt.RtError):
+        core.render_frames(cams + cams[:1], w, h)
+
+
+def test_frame_groups_on_the_gpu_single_rank(core, ob, rt, car_xyz9):
+    """FrameSharder.trace_group with world size 1: one launch, one assemble per group of frames, two groups in flight."""
+    from ray_tracer_amd import sharding
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    core.set_scene(None, tris)
+    core.set_materials(None)
+    core.build_grid()
+    scene = ob.Scene(None, tris)
+    w, h = 300, 170
+    cams = [rt.Camera((200.0 - 20 * j, 200.0, 300.0 - 10 * j), 3.35 + 0.02 * j, -0.28).to_uniform(0.0, float(h)) for j in range(7)]
+    sh = sharding.FrameSharder(core, w, h, 64, 64, rank=0, world=1, device="cuda", shadow=True, mode="rgba", max_bounces=1)
+    sh.enable_groups(group=4, groups_in_flight=2)
+    a, b = sh.trace_group(cams[:4]), sh.trace_group(cams[4:])
+    sh.synchronize()
+    core.set_stream(None)
+    assert a.shape == (4, w * h, 4) and b.shape == (3, w * h, 4)
+    for j, pic in enumerate(list(a) + list(b)):
+        want, _ = ob.render(scene, ocam(ob, cams[j]), w, h, max_bounces=1, shadows=True)
+        assert np.array_equal(pic.cpu().numpy(), want), f"frame {j}"
+
+
 def test_alpha_rules_hit_records_and_picture(core, ob, rt, car_xyz9):
     """Untextured alpha MASK / BLEND materials (raytracer_unified.wgsl:310-321) remove triangles from every
     ray's view; set before the grid, after it, and taken away again."""

@@ -35,6 +35,16 @@ class OracleCore:
                                 n_threads=2)
         out[:len(img)] = torch.from_numpy(img)
 
+    def render_frames(self, cams, width, height, shard=None, max_bounces=8, shadows=False, out=None):
+        for j, cam in enumerate(cams):
+            self.render(cam, width, height, shard=shard, max_bounces=max_bounces, shadows=shadows, out=out[j])
+
+    def assemble_frames_rgba8(self, gathered, width, height, tile_w, tile_h, n_ranks, n_frames, rank_stride, frame_stride,
+                              images):
+        flat = gathered.reshape(-1, 4)
+        for j in range(n_frames):
+            self._assemble(flat[j * frame_stride:], width, height, tile_w, tile_h, n_ranks, images[j], rank_stride, torch.uint8, 4)
+
     def set_stream(self, stream):
         pass
 
@@ -97,6 +107,19 @@ def _worker(rank, world, port, tmp):
                 ok2 = ok2 and np.array_equal(pic.numpy(), want)
             ok2 = ok2 and pics[0] is pics[2] and pics[0] is not pics[1]
             open(os.path.join(tmp, "result_rgba"), "w").write(str(int(ok2)))
+        # groups of frames: one launch, one gather, one assemble per group; a full group, then a partial one
+        shg = sharding.FrameSharder(OracleCore(ob, scene), W, H, TW, TH, device="cpu", shadow=False, mode="rgba", max_bounces=1)
+        shg.enable_groups(group=3, groups_in_flight=2)
+        cams = [cam, cam2, ob.camera_to_uniform((150, 120, 250), 3.4, -0.3, 0.0, float(H)), cam2, cam]
+        first, second = shg.trace_group(cams[:3]), shg.trace_group(cams[3:])
+        if rank == 0:
+            ok3 = first.shape == (3, W * H, 4) and second.shape == (2, W * H, 4)
+            for c, pic in zip(cams, list(first) + list(second)):
+                want, _ = ob.render(scene, c, W, H, max_bounces=1, n_threads=2)
+                ok3 = ok3 and np.array_equal(pic.numpy(), want)
+            open(os.path.join(tmp, "result_groups"), "w").write(str(int(ok3)))
+        else:
+            assert first is None and second is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -114,6 +137,7 @@ def test_frame_sharding_two_ranks_gloo(tmp_path, world):
     ok, hits = open(tmp_path / "result").read().split()
     assert ok == "1" and int(hits) > 1000
     assert open(tmp_path / "result_rgba").read() == "1"
+    assert open(tmp_path / "result_groups").read() == "1"
 
 
 def test_tile_bookkeeping():

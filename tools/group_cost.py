@@ -1,0 +1,69 @@
+"""Development aid: what one rank of an N-GPU run spends per 1080p frame on its own GPU (no collective): its tiles of
+GROUP frames per launch, groups in flight on separate streams, plus rank 0's assemble. Gives the compute-side bound of
+the N-GPU frame rate; the link-side bound is (N-1)/N * 8.3 MB per frame into rank 0."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ray_tracer_amd as rt  # noqa: E402
+from ray_tracer_amd import sharding  # noqa: E402
+
+W, H = 1920, 1080
+TILE = int(os.environ.get("RT_TILE", "64"))
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    xyz9 = np.load(os.path.join(ROOT, "tests", "golden", "car_tris.npy"))
+    core = rt.TraceCore(0)
+    core.set_scene(None, rt.triangles_from_xyz9(xyz9))
+    core.build_grid()
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
+    out = []
+    for world in [int(x) for x in os.environ.get('RT_WORLDS', '1,2,4,8').split(',')]:
+        for group, in_flight in ((1, 4), (4, 3), (8, 3), (16, 2)) if 'RT_QUICK' not in os.environ else ((8, 3), (16, 2)):
+            per_rank = []
+            for rank in range(world):
+                sh = sharding.FrameSharder(core, W, H, TILE, TILE, rank=rank, world=1, device=dev, shadow=True, mode="rgba", max_bounces=1)
+                sh.shard = rt.RtShard(TILE, TILE, rank, world)  # this rank's tiles of a `world`-GPU run, no gather
+                sh.per_rank = sharding.per_rank_pixels(W, H, TILE, TILE, world)
+                sh.enable_groups(group, in_flight)
+                cams = [cam] * group
+                slots = sh.gslots
+                def run(n):
+                    for k in range(n):
+                        slot = slots[k % len(slots)]
+                        core.set_stream(slot.stream.cuda_stream)
+                        core.render_frames(cams, W, H, shard=sh.shard, max_bounces=1, shadows=True, out=slot.local)
+                    core.sync()
+                run(10)
+                n = max(10, 400 // group)
+                t0 = time.perf_counter()
+                run(n)
+                per_rank.append((time.perf_counter() - t0) / (n * group) * 1e6)
+                core.set_stream(None)
+            out.append({"world": world, "group": group, "groups_in_flight": in_flight, "us_per_frame_by_rank": [round(x, 1) for x in per_rank],
+                        "slowest_rank_us": round(max(per_rank), 1), "speedup_bound": round(out[0]["slowest_rank_us"] / max(per_rank), 2) if out else 1.0})
+            print(json.dumps(out[-1]), flush=True)
+    # rank 0's assemble of one group of 8 frames
+    g = 8
+    packed = torch.zeros((8, g, sharding.per_rank_pixels(W, H, TILE, TILE, 8), 4), dtype=torch.uint8, device=dev)
+    images = torch.empty((g, W * H, 4), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        core.assemble_frames_rgba8(packed, W, H, TILE, TILE, 8, g, g * packed.shape[2], packed.shape[2], images)
+    core.sync()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        core.assemble_frames_rgba8(packed, W, H, TILE, TILE, 8, g, g * packed.shape[2], packed.shape[2], images)
+    core.sync()
+    print(json.dumps({"assemble_us_per_frame": round((time.perf_counter() - t0) / 50 / g * 1e6, 2)}))
+
+
+if __name__ == "__main__":
+    main()

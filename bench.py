@@ -172,6 +172,8 @@ def main():
         sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
                                    frames_in_flight=1, max_bounces=1)
         sh.enable_groups(GROUP, GROUPS_IN_FLIGHT)
+        sh.trace_group([cam])  # set-up, untimed: the first collective creates the RCCL communicator
+        sh.synchronize()
         pending = []
 
         def step():

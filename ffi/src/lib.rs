@@ -42,6 +42,10 @@ extern "C" {
     pub fn rt_set_stream(ctx: *mut RtCtx, hip_stream: *mut c_void) -> c_int;
     pub fn rt_set_materials(ctx: *mut RtCtx, materials: *const c_void, n: u32) -> c_int;
     pub fn rt_set_textures(ctx: *mut RtCtx, textures: *const RtTexture, n: u32) -> c_int;
+    pub fn rt_render_frames(ctx: *mut RtCtx, cameras: *const c_void, n_frames: u32, width: u32, height: u32,
+                            shard: *const c_void, opts: *const c_void, out_rgba8: *mut u8) -> c_int;
+    pub fn rt_assemble_frames_rgba8(ctx: *mut RtCtx, gathered: *const u8, width: u32, height: u32, tile_w: u32, tile_h: u32,
+                                    n_ranks: u32, n_frames: u32, rank_stride: usize, frame_stride: usize, images: *mut u8) -> c_int;
     pub fn rt_set_skin(ctx: *mut RtCtx, positions: *const f32, joints: *const u16, weights: *const f32, n_vertices: u32,
                        tri_indices: *const u32, n_triangles: u32) -> c_int;
     pub fn rt_skin_vertices(ctx: *mut RtCtx, joint_matrices: *const f32, n_joints: u32) -> c_int;

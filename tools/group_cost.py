@@ -15,7 +15,7 @@ import ray_tracer_amd as rt  # noqa: E402
 from ray_tracer_amd import sharding  # noqa: E402
 
 W, H = 1920, 1080
-TILE = int(os.environ.get("RT_TILE", "64"))
+TILE = int(os.environ.get("RT_TILE", "32"))
 
 
 def main():

@@ -366,7 +366,22 @@ void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const D
 #ifdef RT_EXPERIMENTS
     if (const char* v = getenv("RT_VARIANT")) {
         if (!WGSL && SHADOW && !stats && s.nb == 0) {
-            switch (atoi(v)) {
+            const int vn = atoi(v);
+            if (vn >= 40 && vn < 60) {  // persistent waves: one wave per wave slot of the chip
+                void* q = nullptr;
+                if (hipGetSymbolAddress(&q, HIP_SYMBOL(rt::g_queue)) != hipSuccess) return;
+                (void)hipMemsetAsync(q, 0, sizeof(uint32_t), c->stream);
+                const uint32_t n_waves = grid.x * 4;
+                switch (vn) {
+                    case 41: hipLaunchKernelGGL((k_trace_primary_persist<41>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
+                    case 44: hipLaunchKernelGGL((k_trace_primary_persist<44>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
+                    case 40: hipLaunchKernelGGL((k_trace_primary_persist<40>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
+                    case 54: hipLaunchKernelGGL((k_trace_primary_persist<54>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
+                    default: hipLaunchKernelGGL((k_trace_primary_persist<50>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
+                }
+                return;
+            }
+            switch (vn) {
 #define RT_VAR(N) case N: hipLaunchKernelGGL((k_trace_primary_var<N>), dim3(grid.x * (256 / VarCfg<N>::threads)), dim3(VarCfg<N>::threads), 0, c->stream, s, f, m, op, os); return;
                 RT_VARIANT_LIST
 #undef RT_VAR
@@ -1232,6 +1247,14 @@ extern "C" int rt_intersect_tri_pairs_watertight(rt_ctx* c, const float* origins
 }
 
 #ifdef RT_EXPERIMENTS
+// development only: the order in which the persistent variants 5x hand out 8x8 pixel blocks
+extern "C" int rt_dbg_set_order(rt_ctx* c, const uint32_t* order, size_t n) {
+    if (int r = use(c)) return r;
+    if (n > 65536) return fail(c, RT_ERR_LIMIT, "rt_dbg_set_order: at most 65536 blocks");
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(rt::g_order), order, n * sizeof(uint32_t)));
+    return RT_OK;
+}
 // development only: per-wave timestamps of the instrumented variant
 extern "C" int rt_dbg_wave_times(rt_ctx* c, unsigned long long* out, size_t n) {
     if (int r = use(c)) return r;

@@ -6,6 +6,9 @@
 //   body 1..9   trace_ray_x<body> below (whatever is being tried)
 //   0x          four waves per workgroup (shipped)      1x  one wave per workgroup
 //   2x          __launch_bounds__(256, 8)               3x  per-wave start/end timestamps into g_wave_t
+//   4x          persistent waves: 2048 workgroups (every wave slot of the chip once), each wave takes the next 8x8
+//               pixel block from an atomic counter until none is left
+//   5x          the same, blocks handed out in the order of g_order (e.g. most expensive first)
 #pragma once
 #include "rt_trace.hpp"
 
@@ -28,14 +31,51 @@ struct VarCfg {
     static constexpr int min_waves = (VARIANT >= 20 && VARIANT < 30) ? 8 : 1;
 };
 
+__device__ uint32_t g_queue;         // next block of the persistent variants (zeroed before every launch)
+__device__ uint32_t g_order[65536];  // block handed out at each queue position (variants 5x)
+
+template <int VARIANT>
+__device__ inline void trace_block(const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* __restrict__ out_p,
+                                   uint2* __restrict__ out_s, uint32_t gw);
+
 template <int VARIANT>
 __global__ __launch_bounds__(VarCfg<VARIANT>::threads, VarCfg<VARIANT>::min_waves) void k_trace_primary_var(
     DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p, uint2* __restrict__ out_s) {
+    const uint32_t gw = VarCfg<VARIANT>::threads == 64 ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave
+    trace_block<VARIANT>(s, f, m, out_p, out_s, gw);
+}
+
+// Persistent waves: every wave reaches the exit test (chunk >= n_chunks) after finitely many blocks. A wave takes
+// CHUNK queue positions per atomic (same-address device-scope atomics complete at about one per 15 ns on this chip:
+// one atomic per 8x8 block made the launch four times slower than the plain grid). Chunk c holds positions
+// c, c + n_chunks, c + 2 n_chunks, ...: with a cost-sorted order every wave starts with an expensive block and ends
+// with cheap ones.
+template <int VARIANT>
+__global__ __launch_bounds__(256) void k_trace_primary_persist(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
+                                                               uint2* __restrict__ out_s, uint32_t n_waves) {
+    constexpr uint32_t CHUNK = (VARIANT % 10) ? (VARIANT % 10) : 8;
+    const uint32_t n_chunks = (n_waves + CHUNK - 1) / CHUNK;
+    for (;;) {
+        uint32_t c = 0;
+        if ((threadIdx.x & 63) == 0) c = atomicAdd(&g_queue, 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= n_chunks) break;
+        for (uint32_t j = 0; j < CHUNK; ++j) {
+            const uint32_t q = c + j * n_chunks;
+            if (q >= n_waves) break;
+            const uint32_t gw = VARIANT >= 50 ? g_order[q] : q;
+            if (gw < n_waves) trace_block<(VARIANT / 10) * 10>(s, f, m, out_p, out_s, gw);
+        }
+    }
+}
+
+template <int VARIANT>
+__device__ inline void trace_block(const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* __restrict__ out_p,
+                                   uint2* __restrict__ out_s, uint32_t gw) {
     constexpr int BODY = VarCfg<VARIANT>::body;
     constexpr bool STAMPS = VarCfg<VARIANT>::stamps;
     const unsigned long long t_start = STAMPS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t gw = VarCfg<VARIANT>::threads == 64 ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave
     const uint32_t w4 = gw & 3, b16 = gw >> 2;
     const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;
     const uint32_t blk_per_tile = blk_x * blk_y;

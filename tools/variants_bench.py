@@ -26,6 +26,23 @@ os.environ.pop("RT_VARIANT", None)
 core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
 core.sync()
 ref_p, ref_s = p.clone(), s.clone()
+if any(v >= 50 for v in variants):
+    # hand-out order of the persistent variants 5x: most expensive 8x8 block first, by the wave times of a launch of
+    # the instrumented variant 30 (which must be in the build: make exp VARS="0 30 ...")
+    import ctypes as C
+    from ray_tracer_amd import _lib
+    nw = ((W + 15) // 16) * ((H + 15) // 16) * 4
+    os.environ["RT_VARIANT"] = "30"
+    for _ in range(2):
+        core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
+    core.sync()
+    buf = np.zeros(2 * nw, np.uint64)
+    L = _lib.load()
+    L.rt_dbg_wave_times(core._h, buf.ctypes.data_as(C.c_void_p), C.c_size_t(2 * nw))
+    dur = buf[1::2].astype(np.int64) - buf[0::2].astype(np.int64)
+    order = np.argsort(-dur, kind="stable").astype(np.uint32)
+    L.rt_dbg_set_order(core._h, order.ctypes.data_as(C.c_void_p), C.c_size_t(nw))
+    print(f"order from {nw} wave times: longest {dur.max() / 100:.1f} us, mean {dur.mean() / 100:.2f} us")
 times = {v: [] for v in variants}
 for v in variants:
     os.environ["RT_VARIANT"] = str(v)

@@ -13,7 +13,7 @@ pub const RT_MISS: u32 = 0xFFFF_FFFF;
 pub struct RtParams {
     pub finest_cell_size: f32, pub max_objects_per_cell: u32, pub max_dda_steps: u32, pub wgsl_compat: u32,
     pub lod_cull: u32, pub moving_box_count: u32, pub fov: f32, pub light_direction: [f32; 3],
-    pub shadow_offset: f32, pub collect_stats: u32,
+    pub shadow_offset: f32, pub collect_stats: u32, pub skip_duplicate_triangles: u32,
 }
 
 #[repr(C)]
@@ -41,6 +41,7 @@ extern "C" {
                          out: *mut RtHit, any_hit: c_int) -> c_int;
     pub fn rt_set_stream(ctx: *mut RtCtx, hip_stream: *mut c_void) -> c_int;
     pub fn rt_set_materials(ctx: *mut RtCtx, materials: *const c_void, n: u32) -> c_int;
+    pub fn rt_get_trace_refs(ctx: *mut RtCtx, n_trace_refs: *mut u32) -> c_int;
     pub fn rt_set_textures(ctx: *mut RtCtx, textures: *const RtTexture, n: u32) -> c_int;
     pub fn rt_render_frames(ctx: *mut RtCtx, cameras: *const c_void, n_frames: u32, width: u32, height: u32,
                             shard: *const c_void, opts: *const c_void, out_rgba8: *mut u8) -> c_int;

@@ -69,6 +69,14 @@ typedef struct rt_params {
     float light_direction[3];      /* (0.5,-1,0.3)    raytracer_unified.wgsl:5 */
     float shadow_offset;           /* 0.001           raytracer_unified.wgsl:687 */
     uint32_t collect_stats;        /* 0; 1 = count cells/candidates (slower kernels) */
+    uint32_t skip_duplicate_triangles; /* 1: grids built by rt_build_grid leave a triangle out of the records the
+                                         trace walks when a triangle with a lower id has bit-identical vertices and
+                                         no alpha rule of its own: the copy is met right after the original in every
+                                         cell list, yields the same t, and under the shader's strict '<' can neither
+                                         replace it nor be accepted where it was rejected, so no ray's answer changes.
+                                         (The reference's benchmark scene repeats 10 000 triangle positions.)
+                                         rt_read_grid_csr / rt_get_grid still report the reference's full lists, and
+                                         the counting kernels (collect_stats) walk them. 0: every list entry is tested */
 } rt_params;
 
 /* Which pixels of a W x H frame one call traces. The frame is cut into
@@ -150,6 +158,9 @@ int rt_build_grid(rt_ctx* ctx, float cell_size, uint32_t max_per_cell, int mode)
 
 /* Metadata and sizes of the current grid. */
 int rt_get_grid(rt_ctx* ctx, GridMetadata* meta, uint32_t* n_cells, uint32_t* n_refs);
+/* Number of reference records the trace kernels walk for the current grid: n_refs of rt_get_grid minus the
+ * references left out by params.skip_duplicate_triangles. No reference counterpart. */
+int rt_get_trace_refs(rt_ctx* ctx, uint32_t* n_trace_refs);
 /* Copies the current grid's cell list back to the host: cell_start[n_cells+1], indices[n_refs]. */
 int rt_read_grid_csr(rt_ctx* ctx, uint32_t* cell_start, uint32_t* indices);
 

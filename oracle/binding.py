@@ -51,11 +51,11 @@ class Params(C.Structure):
     _fields_ = [("finest_cell_size", C.c_float), ("max_objects_per_cell", C.c_uint32), ("max_dda_steps", C.c_uint32),
                 ("wgsl_compat", C.c_uint32), ("lod_cull", C.c_uint32), ("moving_box_count", C.c_uint32),
                 ("fov", C.c_float), ("light_direction", C.c_float * 3), ("shadow_offset", C.c_float),
-                ("collect_stats", C.c_uint32)]
+                ("collect_stats", C.c_uint32), ("skip_duplicate_triangles", C.c_uint32)]
 
     @classmethod
     def default(cls, **kw):
-        p = cls(16.0, 8192, 200, 0, 1, 3, 0.785398, (C.c_float * 3)(0.5, -1.0, 0.3), 0.001, 0)
+        p = cls(16.0, 8192, 200, 0, 1, 3, 0.785398, (C.c_float * 3)(0.5, -1.0, 0.3), 0.001, 0, 1)
         for k, v in kw.items():
             setattr(p, k, v)
         return p

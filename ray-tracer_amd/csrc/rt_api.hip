@@ -247,7 +247,7 @@ DevScene make_scene(const rt_ctx* c) {
     s.nb = c->grid_nb;
     s.nt = c->nt;
     s.n_cells = c->n_cells;
-    s.n_refs = c->n_refs;
+    s.n_refs = c->n_refs_t;
     s.gx = c->meta.grid_sizes[RT_GRID_LEVELS - 1][0];
     s.gy = c->meta.grid_sizes[RT_GRID_LEVELS - 1][1];
     s.gz = c->meta.grid_sizes[RT_GRID_LEVELS - 1][2];
@@ -446,9 +446,9 @@ int stage_in(rt_ctx* c, DevBuf& buf, const void* src, size_t bytes, const void**
 namespace rt {
 
 int apply_visibility(rt_ctx* c) {
-    if (!c->n_refs || !c->nt) return RT_OK;
-    hipLaunchKernelGGL(k_ref_visibility, dim3((c->n_refs + 255) / 256), dim3(256), 0, c->stream, c->indices.as<uint32_t>(),
-                       c->n_refs, c->grid_nb, c->nt, c->tri_mat.as<uint32_t>(), c->materials.as<float4>(), c->n_materials,
+    if (!c->n_refs_t || !c->nt) return RT_OK;
+    hipLaunchKernelGGL(k_ref_visibility, dim3((c->n_refs_t + 255) / 256), dim3(256), 0, c->stream, c->t_indices,
+                       c->n_refs_t, c->grid_nb, c->nt, c->tri_mat.as<uint32_t>(), c->materials.as<float4>(), c->n_materials,
                        c->refs.as<float4>());
     RT_HIP(c, hipGetLastError());
     return RT_OK;
@@ -461,13 +461,13 @@ int emit_refs_from_csr(rt_ctx* c) {
         return fail(c, RT_ERR_LIMIT, "grid of %u x %u x %u cells: the bordered cell array has %llu entries (max 2^32-1)",
                     g[0], g[1], g[2], bordered);
     RT_HIP(c, c->cells.reserve((size_t)bordered * sizeof(uint2)));
-    RT_HIP(c, c->refs.reserve(((size_t)c->n_refs * 3 + 3) * sizeof(float4)));
+    RT_HIP(c, c->refs.reserve(((size_t)c->n_refs_t * 3 + 3) * sizeof(float4)));
     hipLaunchKernelGGL(k_emit_cells, dim3((unsigned)((bordered + 255) / 256)), dim3(256), 0, c->stream,
-                       c->cell_start.as<uint32_t>(), g[0], g[1], g[2], c->cells.as<uint2>());
+                       c->t_cell_start, g[0], g[1], g[2], c->cells.as<uint2>());
     RT_HIP(c, hipGetLastError());
-    if (c->n_refs) {
-        hipLaunchKernelGGL(k_emit_refs, dim3((c->n_refs + 255) / 256), dim3(256), 0, c->stream,
-                           c->indices.as<uint32_t>(), c->n_refs, c->tri_v.as<float>(), c->grid_nb, c->nt,
+    if (c->n_refs_t) {
+        hipLaunchKernelGGL(k_emit_refs, dim3((c->n_refs_t + 255) / 256), dim3(256), 0, c->stream,
+                           c->t_indices, c->n_refs_t, c->tri_v.as<float>(), c->grid_nb, c->nt,
                            c->refs.as<float4>());
         RT_HIP(c, hipGetLastError());
     }
@@ -492,6 +492,7 @@ extern "C" void rt_default_params(rt_params* p) {
     p->light_direction[2] = 0.3f;
     p->shadow_offset = 0.001f;
     p->collect_stats = 0;
+    p->skip_duplicate_triangles = 1;
 }
 
 extern "C" const char* rt_create_error(void) { return g_create_error.c_str(); }
@@ -555,7 +556,8 @@ extern "C" void rt_destroy(rt_ctx* c) {
                       &c->skin_weights, &c->skin_tri, &c->skin_mats, &c->bvh_nodes, &c->bvh_leaf_first, &c->bvh_prims, &c->bvh_recs,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
                       &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->b_obj_n, &c->b_obj_off, &c->b_obj_sum, &c->out_p,     &c->out_s,
-                      &c->in_o,      &c->in_d,      &c->stats,      &c->misc,      &c->tri_uv,    &c->texels};
+                      &c->in_o,      &c->in_d,      &c->stats,      &c->misc,      &c->tri_uv,    &c->texels,    &c->tc_start,  &c->tc_indices, &c->tc_pos, &c->dd_keys, &c->dd_keys2,
+                      &c->dd_vals, &c->dd_vals2, &c->dd_flag, &c->dd_head, &c->dd_dup};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -601,7 +603,16 @@ extern "C" int rt_sync(rt_ctx* c) {
 
 extern "C" int rt_set_collect_stats(rt_ctx* c, int enabled) {
     if (int r = use(c)) return r;
-    c->params.collect_stats = enabled ? 1u : 0u;
+    const uint32_t v = enabled ? 1u : 0u;
+    if (v == c->params.collect_stats) return RT_OK;
+    c->params.collect_stats = v;
+    // the counting kernels walk the reference's full lists
+    if (c->has_grid && c->grid_built && c->params.skip_duplicate_triangles) {
+        if (int r = scene_barrier(c)) return r;
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        if (int r = rebuild_trace_records(c)) return r;
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return RT_OK;
 }
 
@@ -637,6 +648,7 @@ extern "C" int rt_set_scene(rt_ctx* c, const BoxData* boxes, uint32_t nb, const 
     if ((uint64_t)nb + nt >= 0xFFFFFFF0ull) return fail(c, RT_ERR_LIMIT, "rt_set_scene: more than 2^32-16 objects");
     if (int r = scene_barrier(c)) return r;
     c->has_grid = false;
+    c->dup_state = -1;
     c->has_skin = false;  // a skin belongs to the triangles it was set for
     c->has_bvh = false;
     c->nb = nb;
@@ -688,7 +700,8 @@ static int install_csr(rt_ctx* c, const GridMetadata* meta, const uint32_t* cell
     RT_HIP(c, hipMemcpyAsync(c->cell_start.p, cell_start, (n_cells + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if (n_refs)
         RT_HIP(c, hipMemcpyAsync(c->indices.p, indices, (size_t)n_refs * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    if (int r = emit_refs_from_csr(c)) return r;
+    c->grid_built = false;  // the caller's lists: any order, any content - every entry is tested, none skipped
+    if (int r = rebuild_trace_records(c)) return r;
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->has_grid = true;
     return RT_OK;
@@ -753,6 +766,14 @@ extern "C" int rt_get_grid(rt_ctx* c, GridMetadata* meta, uint32_t* n_cells, uin
     if (meta) *meta = c->meta;
     if (n_cells) *n_cells = c->n_cells;
     if (n_refs) *n_refs = c->n_refs;
+    return RT_OK;
+}
+
+extern "C" int rt_get_trace_refs(rt_ctx* c, uint32_t* n_trace_refs) {
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_get_trace_refs: no grid");
+    if (!n_trace_refs) return fail(c, RT_ERR_INVALID, "rt_get_trace_refs: NULL argument");
+    *n_trace_refs = c->n_refs_t;
     return RT_OK;
 }
 
@@ -1012,6 +1033,7 @@ extern "C" int rt_set_materials(rt_ctx* c, const MaterialData* materials, uint32
     RT_HIP(c, c->materials.reserve((size_t)n * sizeof(MaterialData) + 16));
     if (n) RT_HIP(c, hipMemcpyAsync(c->materials.p, materials, (size_t)n * sizeof(MaterialData), hipMemcpyHostToDevice, c->stream));
     c->n_materials = n;
+    c->dup_state = -1;  // which copies may be left out depends on the originals' alpha rules
     c->tex_mode = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const MaterialData& m = materials[i];
@@ -1019,8 +1041,10 @@ extern "C" int rt_set_materials(rt_ctx* c, const MaterialData* materials, uint32
         if (c->tex_mode < 1 && (m.texture_index >= 0 || m.normal_texture_index >= 0 || m.emissive_texture_index >= 0))
             c->tex_mode = 1;
     }
-    if (c->has_grid)
-        if (int r = apply_visibility(c)) return r;
+    if (c->has_grid) {
+        // which duplicates may be left out depends on the materials; otherwise only the id / material words change
+        if (int r = c->grid_built && c->params.skip_duplicate_triangles ? rebuild_trace_records(c) : apply_visibility(c)) return r;
+    }
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

@@ -168,9 +168,12 @@ __global__ __launch_bounds__(256) void k_bin(BinGrid g, const BoxData* __restric
 // trace kernel skips it. T's cells form a box and a line crosses a box in one run of face-adjacent cells, so
 // "listed one step back" is the same as "already tested". Cells whose lists may have been cut by the per-cell
 // cap never vouch for their neighbours (their bits stay 0), which keeps the skip exact.
+// cell_start / indices: the lists the records were made from; full_start: the reference's lists (whether a cell
+// was cut by the cap is a property of those).
 __global__ void k_ref_masks(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
                             const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ indices,
-                            uint32_t n_refs, uint32_t n_cells, uint32_t cap, float4* __restrict__ refs) {
+                            const uint32_t* __restrict__ full_start, uint32_t n_refs, uint32_t n_cells, uint32_t cap,
+                            float4* __restrict__ refs) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_refs) return;
     // cell of this reference: last c with cell_start[c] <= r
@@ -189,11 +192,11 @@ __global__ void k_ref_masks(BinGrid g, const BoxData* __restrict__ boxes, const 
     for (int a = 0; a < 3; ++a) {
         if ((int)cc[a] > rg.lo[a]) {  // arrived by a + step: previous cell is c - stride
             const uint32_t p = c - stride[a];
-            if (cell_start[p + 1] - cell_start[p] < cap) mask |= 1u << (2 * a);
+            if (full_start[p + 1] - full_start[p] < cap) mask |= 1u << (2 * a);
         }
         if ((int)cc[a] < rg.hi[a]) {  // arrived by a - step: previous cell is c + stride
             const uint32_t p = c + stride[a];
-            if (cell_start[p + 1] - cell_start[p] < cap) mask |= 2u << (2 * a);
+            if (full_start[p + 1] - full_start[p] < cap) mask |= 2u << (2 * a);
         }
     }
     refs[3 * (size_t)r + 1].w = __uint_as_float(mask);
@@ -216,9 +219,167 @@ __global__ void k_compact(const uint32_t* __restrict__ sorted, const uint32_t* _
     if (j < cap) indices[final_start[c] + j] = sorted[r];
 }
 
+// ---- duplicate triangles -------------------------------------------------------------------------------
+// A triangle whose nine vertex words equal those of a triangle with a lower id is met right after it in every cell
+// list (same bounds, same cells; lists are ascending and the cap keeps the lowest ids) and gives the same t. The
+// shader replaces the closest hit only when t is strictly smaller, so the copy can neither win nor be accepted
+// where the original was rejected - provided the original's acceptance depends on geometry alone (no alpha rule).
+
+__global__ void k_tri_hash(const float* __restrict__ tri_v, uint32_t nt, unsigned long long* __restrict__ keys,
+                           uint32_t* __restrict__ vals) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nt) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(tri_v) + 9 * (size_t)k;
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 9; ++i) {
+        h ^= w[i];
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 29;
+    }
+    keys[k] = h;
+    vals[k] = k;
+}
+
+__global__ void k_run_heads(const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ flag) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    flag[p] = (p == 0 || keys[p] != keys[p - 1]) ? p : 0u;
+}
+
+__global__ void k_mark_duplicates(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ head, uint32_t nt,
+                                  const float* __restrict__ tri_v, const uint32_t* __restrict__ tri_mat,
+                                  const float4* __restrict__ materials, uint32_t n_materials, uint32_t* __restrict__ dup) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nt) return;
+    const uint32_t k = vals[p], j = vals[head[p]];  // j: lowest id with this key (the sort is stable)
+    uint32_t d = 0;
+    if (j < k) {
+        const uint32_t* a = reinterpret_cast<const uint32_t*>(tri_v) + 9 * (size_t)k;
+        const uint32_t* b = reinterpret_cast<const uint32_t*>(tri_v) + 9 * (size_t)j;
+        bool same = true;
+        for (int i = 0; i < 9; ++i) same = same && a[i] == b[i];
+        bool plain = true;  // the original's acceptance depends on geometry alone
+        const uint32_t mat = tri_mat[j];
+        if (mat < n_materials) {
+            const uint32_t mode = __float_as_uint(materials[4 * mat + 3].x);
+            plain = mode != 1u && mode != 2u;
+        }
+        d = same && plain ? 1u : 0u;
+    }
+    dup[k] = d;
+}
+
+__global__ void k_keep_flags(const uint32_t* __restrict__ indices, uint32_t n_refs, uint32_t nb, uint32_t nt,
+                             const uint32_t* __restrict__ dup, uint32_t* __restrict__ keep) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_refs) return;
+    uint32_t v = 0;
+    if (r < n_refs) {
+        const uint32_t id = indices[r];
+        v = (id >= nb && id - nb < nt && dup[id - nb]) ? 0u : 1u;
+    }
+    keep[r] = v;  // entry n_refs closes the scan
+}
+
+__global__ void k_compact_refs(const uint32_t* __restrict__ indices, const uint32_t* __restrict__ pos, uint32_t n_refs,
+                               uint32_t* __restrict__ out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_refs) return;
+    if (pos[r + 1] != pos[r]) out[pos[r]] = indices[r];
+}
+
+__global__ void k_compact_starts(const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ pos, uint32_t n_cells,
+                                 uint32_t* __restrict__ out) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= n_cells) out[c] = pos[cell_start[c]];
+}
+
 }  // namespace
 
 namespace rt {
+
+int rebuild_trace_records(rt_ctx* c) {
+    hipStream_t st = c->stream;
+    c->t_cell_start = c->cell_start.as<uint32_t>();
+    c->t_indices = c->indices.as<uint32_t>();
+    c->n_refs_t = c->n_refs;
+    const uint32_t nb = c->grid_nb, nt = c->nt, n_refs = c->n_refs, n_cells = c->n_cells;
+    // Only for lists this library built (lowest ids survive the cap), when the shader's own cap does not cut them
+    // further, and not for the counting kernels, which walk what the reference walks.
+    const bool dedup = c->grid_built && c->params.skip_duplicate_triangles && !c->params.collect_stats && nt > 1 && n_refs > 0 &&
+                       c->params.max_objects_per_cell >= c->build_cap && c->dup_state != 0;
+    if (dedup) {
+        RT_HIP(c, c->dd_keys.reserve((size_t)nt * 8));
+        RT_HIP(c, c->dd_keys2.reserve((size_t)nt * 8));
+        RT_HIP(c, c->dd_vals.reserve((size_t)nt * 4));
+        RT_HIP(c, c->dd_vals2.reserve((size_t)nt * 4));
+        RT_HIP(c, c->dd_flag.reserve(std::max((size_t)nt, (size_t)n_refs + 1) * 4));  // run heads, then keep flags
+        RT_HIP(c, c->dd_head.reserve((size_t)nt * 4));
+        RT_HIP(c, c->dd_dup.reserve((size_t)nt * 4));
+        unsigned long long* keys = c->dd_keys.as<unsigned long long>();
+        unsigned long long* keys2 = c->dd_keys2.as<unsigned long long>();
+        uint32_t *vals = c->dd_vals.as<uint32_t>(), *vals2 = c->dd_vals2.as<uint32_t>();
+        uint32_t *flag = c->dd_flag.as<uint32_t>(), *head = c->dd_head.as<uint32_t>(), *dup = c->dd_dup.as<uint32_t>();
+        const dim3 tg((nt + 255) / 256);
+        hipLaunchKernelGGL(k_tri_hash, tg, dim3(256), 0, st, c->tri_v.as<float>(), nt, keys, vals);
+        RT_HIP(c, hipGetLastError());
+        size_t bytes = 0;
+        RT_HIP(c, rocprim::radix_sort_pairs(nullptr, bytes, keys, keys2, vals, vals2, (size_t)nt, 0, 64, st));
+        RT_HIP(c, c->b_scan_tmp.reserve(bytes + 256));
+        RT_HIP(c, rocprim::radix_sort_pairs(c->b_scan_tmp.p, bytes, keys, keys2, vals, vals2, (size_t)nt, 0, 64, st));
+        hipLaunchKernelGGL(k_run_heads, tg, dim3(256), 0, st, (const unsigned long long*)keys2, nt, flag);
+        RT_HIP(c, hipGetLastError());
+        RT_HIP(c, rocprim::inclusive_scan(nullptr, bytes, flag, head, (size_t)nt, rocprim::maximum<uint32_t>(), st));
+        RT_HIP(c, c->b_scan_tmp.reserve(bytes + 256));
+        RT_HIP(c, rocprim::inclusive_scan(c->b_scan_tmp.p, bytes, flag, head, (size_t)nt, rocprim::maximum<uint32_t>(), st));
+        hipLaunchKernelGGL(k_mark_duplicates, tg, dim3(256), 0, st, (const uint32_t*)vals2, (const uint32_t*)head, nt,
+                           c->tri_v.as<float>(), c->tri_mat.as<uint32_t>(), c->materials.as<float4>(), c->n_materials, dup);
+        RT_HIP(c, hipGetLastError());
+        // which references stay, and where they go
+        RT_HIP(c, c->tc_pos.reserve(((size_t)n_refs + 1) * 4));
+        uint32_t* keep = c->dd_flag.as<uint32_t>();
+        uint32_t* pos = c->tc_pos.as<uint32_t>();
+        hipLaunchKernelGGL(k_keep_flags, dim3((n_refs + 1 + 255) / 256), dim3(256), 0, st, c->indices.as<uint32_t>(), n_refs, nb,
+                           nt, (const uint32_t*)dup, keep);
+        RT_HIP(c, hipGetLastError());
+        RT_HIP(c, rocprim::exclusive_scan(nullptr, bytes, keep, pos, 0u, (size_t)n_refs + 1, rocprim::plus<uint32_t>(), st));
+        RT_HIP(c, c->b_scan_tmp.reserve(bytes + 256));
+        RT_HIP(c, rocprim::exclusive_scan(c->b_scan_tmp.p, bytes, keep, pos, 0u, (size_t)n_refs + 1, rocprim::plus<uint32_t>(), st));
+        uint32_t kept = 0;
+        RT_HIP(c, hipMemcpyAsync(&kept, pos + n_refs, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        RT_HIP(c, hipStreamSynchronize(st));
+        c->dup_state = kept < n_refs ? 1 : 0;
+        if (kept < n_refs) {
+            RT_HIP(c, c->tc_indices.reserve((size_t)kept * 4 + 16));
+            RT_HIP(c, c->tc_start.reserve(((size_t)n_cells + 1) * 4));
+            hipLaunchKernelGGL(k_compact_refs, dim3((n_refs + 255) / 256), dim3(256), 0, st, c->indices.as<uint32_t>(),
+                               (const uint32_t*)pos, n_refs, c->tc_indices.as<uint32_t>());
+            hipLaunchKernelGGL(k_compact_starts, dim3((n_cells + 1 + 255) / 256), dim3(256), 0, st, c->cell_start.as<uint32_t>(),
+                               (const uint32_t*)pos, n_cells, c->tc_start.as<uint32_t>());
+            RT_HIP(c, hipGetLastError());
+            c->t_cell_start = c->tc_start.as<uint32_t>();
+            c->t_indices = c->tc_indices.as<uint32_t>();
+            c->n_refs_t = kept;
+        }
+    }
+    if (int r = emit_refs_from_csr(c)) return r;
+    if (c->grid_built && c->n_refs_t) {
+        BinGrid g;
+        g.bmin[0] = c->meta.bounds_min[0], g.bmin[1] = c->meta.bounds_min[1], g.bmin[2] = c->meta.bounds_min[2];
+        g.cell = c->meta.finest_cell_size;
+        g.gx = c->meta.grid_sizes[RT_GRID_LEVELS - 1][0];
+        g.gy = c->meta.grid_sizes[RT_GRID_LEVELS - 1][1];
+        g.gz = c->meta.grid_sizes[RT_GRID_LEVELS - 1][2];
+        g.nb = nb, g.nt = nt;
+        g.tri_mode = c->grid_mode == RT_GRID_TRIANGLES ? 1 : 0;
+        const uint32_t cap = std::min(c->build_cap, c->params.max_objects_per_cell);
+        hipLaunchKernelGGL(k_ref_masks, dim3((c->n_refs_t + 255) / 256), dim3(256), 0, st, g, c->boxes.as<BoxData>(),
+                           c->tri_v.as<float>(), c->t_cell_start, c->t_indices, (const uint32_t*)c->cell_start.as<uint32_t>(),
+                           c->n_refs_t, n_cells, cap, c->refs.as<float4>());
+        RT_HIP(c, hipGetLastError());
+    }
+    return RT_OK;
+}
 
 int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode) {
     const bool tri_mode = mode == RT_GRID_TRIANGLES;
@@ -408,14 +569,10 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
     c->n_refs = n_refs;
     // a triangle-only grid numbers its triangles from 0 and knows no boxes (src/grid_triangles.rs:92-99)
     c->grid_nb = nb;
-    if (int r = emit_refs_from_csr(c)) return r;
-    if (n_refs) {
-        const uint32_t cap = std::min(max_per_cell, c->params.max_objects_per_cell);
-        hipLaunchKernelGGL(k_ref_masks, dim3((n_refs + 255) / 256), dim3(256), 0, st, g, c->boxes.as<BoxData>(),
-                           c->tri_v.as<float>(), (const uint32_t*)final_start, (const uint32_t*)c->indices.as<uint32_t>(),
-                           n_refs, n_cells, cap, c->refs.as<float4>());
-        RT_HIP(c, hipGetLastError());
-    }
+    c->grid_built = true;
+    c->grid_mode = mode;
+    c->build_cap = max_per_cell;
+    if (int r = rebuild_trace_records(c)) return r;
     RT_HIP(c, hipStreamSynchronize(st));
     return RT_OK;
 }

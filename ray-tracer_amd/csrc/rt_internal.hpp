@@ -83,8 +83,19 @@ struct rt_ctx {
     bool has_grid = false;
     GridMetadata meta;
     uint32_t n_cells = 0, n_refs = 0;
-    rt::DevBuf cell_start;  // u32[n_cells+1]
+    rt::DevBuf cell_start;  // u32[n_cells+1]   the reference's cell lists (what rt_read_grid_csr returns)
     rt::DevBuf indices;     // u32[n_refs]
+    // The lists the trace records are made from: the reference's, or those with duplicate triangles left out.
+    bool grid_built = false;     // produced by rt_build_grid (lists hold the lowest ids, re-test masks are valid)
+    int grid_mode = 0;
+    uint32_t build_cap = 0;
+    uint32_t n_refs_t = 0;
+    // -1: not looked for yet (new scene or materials); 0: the last search left nothing out, so a rebuild after a
+    // vertex update does not search again (an animated mesh pays for one search, not one per frame); 1: found
+    int dup_state = -1;
+    const uint32_t* t_cell_start = nullptr;  // = cell_start or tc_start
+    const uint32_t* t_indices = nullptr;     // = indices or tc_indices
+    rt::DevBuf tc_start, tc_indices, tc_pos, dd_keys, dd_keys2, dd_vals, dd_vals2, dd_flag, dd_head, dd_dup;
     rt::DevBuf cells;       // uint2[n_cells]
     rt::DevBuf refs;        // float4[3*n_refs]
     rt::DevBuf box_frame;   // float4[4*nb]
@@ -137,8 +148,11 @@ inline bool is_device_ptr(const void* p) {
 
 // implemented in rt_build.hip
 int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode);
-// implemented in rt_api.hip: (cell_start, indices) on device -> cells + refs records
+// implemented in rt_api.hip: (t_cell_start, t_indices) on device -> cells + refs records
 int emit_refs_from_csr(rt_ctx* c);
+// implemented in rt_build.hip: trace records (cells, refs, masks, visibility) from the current cell lists,
+// vertices and materials; leaves duplicate triangles out when the grid and the parameters allow it
+int rebuild_trace_records(rt_ctx* c);
 // implemented in rt_api.hip: rewrites the id word of triangle references from the current materials
 int apply_visibility(rt_ctx* c);
 

@@ -276,6 +276,12 @@ class TraceCore:
                                                  rank_stride, _ptr(image)))
 
     # ---- shaded picture
+    def trace_refs(self):
+        """Reference records the trace kernels walk (cell references minus skipped duplicate triangles)."""
+        n = C.c_uint32()
+        self._ck(self._L.rt_get_trace_refs(self._h, C.byref(n)))
+        return n.value
+
     def set_materials(self, materials):
         m = np.ascontiguousarray(materials if materials is not None else np.zeros(0, MATERIAL_DTYPE), MATERIAL_DTYPE)
         self._ck(self._L.rt_set_materials(self._h, _ptr(m), len(m)))

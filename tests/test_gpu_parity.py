@@ -384,6 +384,69 @@ def test_reference_records_beyond_4_gib(core, ob, rt):
     assert np.array_equal(img, ob.render(scene, ocam(ob, cam), w, h, max_bounces=2)[0])
 
 
+def test_duplicate_triangles_are_left_out_exactly(ob, rt):
+    """The reference's benchmark generator repeats its 10 000 positions: copies of a triangle with a lower id are
+    left out of the records the trace walks. Same ids, same t bits as the oracle (which tests every entry), with
+    originals that are invisible or alpha-textured (their copies must stay), through closest-hit, any-hit, the
+    picture and the counting kernels (which walk the full lists)."""
+    from test_oracle_render import alpha_materials
+    tris = ob.generate_test_triangles(35000)  # 10 000 positions, 3 to 4 copies each
+    tris["material_id"] = (np.arange(len(tris)) * 7 // 3) % 6
+    mats = alpha_materials(ob)
+    w, h = 160, 90
+    cam = rt.Camera((20.0, 30.0, 160.0), math.pi + 0.1, -0.15).to_uniform(0.0, float(h))
+    o, d = ob.generate_test_rays(4000)
+    results = {}
+    for skip, use_mats, cell in ((1, True, 16.0), (0, True, 16.0), (1, False, 4.0), (1, True, 4.0)):
+        core = rt.TraceCore(0, rt.default_params(skip_duplicate_triangles=skip))
+        m = mats if use_mats else None
+        if use_mats:
+            core.set_materials(m)  # before the grid
+        scene = setup_scene(core, ob, None, tris, cell_size=cell)  # also checks rt_read_grid_csr against the full lists
+        _, _, n_refs = core.build_grid(cell_size=cell)
+        scene = ob.Scene(None, tris, materials=m, cell_size=cell)
+        n_trace = core.trace_refs()
+        if skip:
+            assert n_trace < (0.8 if use_mats else 0.32) * n_refs, (n_trace, n_refs)
+            if use_mats:  # copies of originals with an alpha rule stay: more records than without materials
+                core.set_materials(None)
+                assert core.trace_refs() < n_trace
+                core.set_materials(m)  # after the grid
+                assert core.trace_refs() == n_trace
+        else:
+            assert n_trace == n_refs
+        gp, gs = core.trace_primary(cam, w, h)
+        op, os_, st = ob.trace_primary(scene, ocam(ob, cam), w, h)
+        assert_hits_equal(gp, op, f"primary skip={skip} mats={use_mats} cell={cell}")
+        assert_hits_equal(gs, os_, f"shadow skip={skip} mats={use_mats} cell={cell}")
+        for any_hit in (False, True):
+            assert_hits_equal(core.trace_rays(o, d, any_hit=any_hit), ob.trace_rays(scene, o, d, any_hit=any_hit)[0], "ray list")
+        img = core.render(cam, w, h, max_bounces=2, shadows=True)
+        assert np.array_equal(img, ob.render(scene, ocam(ob, cam), w, h, max_bounces=2, shadows=True)[0])
+        core.set_collect_stats(True)  # the counting kernels walk the reference's lists
+        assert core.trace_refs() == n_refs
+        gp2, gs2 = core.trace_primary(cam, w, h)
+        got = core.stats()
+        assert {k: got[k] for k in st} == st
+        assert_hits_equal(gp2, op, "primary, counting kernel")
+        core.set_collect_stats(False)
+        assert core.trace_refs() == n_trace
+        assert_hits_equal(core.trace_primary(cam, w, h)[0], op, "primary, after counting")
+        results[(skip, use_mats, cell)] = gp
+        core.close()
+    assert_hits_equal(results[(1, True, 16.0)], results[(0, True, 16.0)], "skip on vs off")
+    # a shader-side cap below the build cap cuts lists after the fact: nothing is left out then
+    core = rt.TraceCore(0, rt.default_params(max_objects_per_cell=7))
+    core.set_scene(None, tris)
+    _, _, n_refs = core.build_grid(cell_size=16.0, max_per_cell=8192)
+    assert core.trace_refs() == n_refs
+    p7 = rt.default_params(max_objects_per_cell=7)
+    gp, gs = core.trace_primary(cam, w, h)
+    op, os_, _ = ob.trace_primary(ob.Scene(None, tris, cell_size=16.0), ocam(ob, cam), w, h, params=oparams(ob, p7))
+    assert_hits_equal(gp, op, "trace-time cap")
+    core.close()
+
+
 def test_stats_equal_oracle_counts(core, ob, rt, car_xyz9):
     scene = setup_scene(core, ob, None, ob.triangles_from_xyz9(car_xyz9))
     cam = rt.Camera.for_scene("gltf").to_uniform(0.0, 135.0)

@@ -89,7 +89,7 @@ def massive(core, sizes):
             ms = timed(core, lambda: core.trace_primary(cam, w, h, out_primary=P[: w * h], out_shadow=S[: w * h]), reps)
             alg = 8 * st["cells_visited"] + 40 * st["tri_tests"] + 8 * st["rays"]
             emit(config="massive_benchmark 3840x2160 primary+shadow", triangles=n, grid=label, dims=list(meta.fine_dims),
-                 cells=n_cells, refs=n_refs, upload_ms=upload_ms, build_ms_first=build_ms, build_ms=build2_ms, trace_ms=ms,
+                 cells=n_cells, refs=n_refs, trace_refs=core.trace_refs(), upload_ms=upload_ms, build_ms_first=build_ms, build_ms=build2_ms, trace_ms=ms,
                  rays=st["rays"], primary_hits=st["primary_hits"], shadow_hits=st["shadow_hits"],
                  Mrays_per_s=st["rays"] / ms / 1e3, tri_tests=st["tri_tests"], Gtests_per_s=st["tri_tests"] / ms / 1e6,
                  algorithmic_GBps=alg / ms / 1e6)

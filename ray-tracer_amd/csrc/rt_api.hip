@@ -607,7 +607,7 @@ extern "C" int rt_set_collect_stats(rt_ctx* c, int enabled) {
     if (v == c->params.collect_stats) return RT_OK;
     c->params.collect_stats = v;
     // the counting kernels walk the reference's full lists
-    if (c->has_grid && c->grid_built && c->params.skip_duplicate_triangles) {
+    if (c->has_grid && c->grid_built && c->params.skip_duplicate_triangles && c->dup_state != 0) {
         if (int r = scene_barrier(c)) return r;
         RT_HIP(c, hipStreamSynchronize(c->stream));
         if (int r = rebuild_trace_records(c)) return r;

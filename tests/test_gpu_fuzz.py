@@ -49,9 +49,11 @@ def random_scene(ob, rng):
 
 def test_random_scenes(rt, ob):
     from test_oracle_render import alpha_materials
-    rng = np.random.default_rng(20251111)
+    import os
+    # RT_FUZZ_SEED / RT_FUZZ_TRIALS: longer soak runs with other seeds (the defaults are what the suite runs)
+    rng = np.random.default_rng(int(os.environ.get("RT_FUZZ_SEED", "20251111")))
     rays = mism = pixels = pix_mism = 0
-    for trial in range(48):
+    for trial in range(int(os.environ.get("RT_FUZZ_TRIALS", "48"))):
         boxes, tris, ext = random_scene(ob, rng)
         kw = dict(wgsl_compat=int(rng.integers(0, 2)), lod_cull=int(rng.integers(0, 2)),
                   max_dda_steps=int(rng.choice([200, 200, 23])), max_objects_per_cell=int(rng.choice([8192, 8192, 5])),

@@ -88,9 +88,11 @@ def test_bundled_models_with_materials_and_textures(rt, ob, core, car_xyz9, phoe
 
 
 def test_random_textured_scenes(rt, ob):
-    rng = np.random.default_rng(777)
+    import os
+    seed, trials = int(os.environ.get("RT_FUZZ_SEED", "777")), int(os.environ.get("RT_FUZZ_TRIALS", "32"))
+    rng = np.random.default_rng(seed)
     rays = pixels = wide = 0
-    for trial in range(32):
+    for trial in range(trials):
         boxes, tris, ext = random_scene(ob, rng)
         if tris is None:
             continue
@@ -141,7 +143,7 @@ def test_random_textured_scenes(rt, ob):
             pixels += w * h
         core.close()
     print(f"random textured scenes: {rays} rays and {pixels} shaded pixels compared, 0 mismatches")
-    assert rays > 100000 and wide >= 1
+    assert rays > 100000 and (wide >= 1 or seed != 777)
 
 
 def test_set_textures_rejects_bad_input(rt, core):

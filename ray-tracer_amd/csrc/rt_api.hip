@@ -1142,6 +1142,11 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
     } else if (c->tex_mode != 0) {  // materials name textures: the general kernel with the material path
         if (wgsl) hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
         else hipLaunchKernelGGL((k_render<false, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+    } else if (o.max_bounces == 1) {  // direct lighting only
+        if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        else if (wgsl) hipLaunchKernelGGL((k_render<true, false, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        else if (has_boxes) hipLaunchKernelGGL((k_render<false, true, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        else hipLaunchKernelGGL((k_render<false, false, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
     } else if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
     else if (wgsl) hipLaunchKernelGGL((k_render<true, false>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
     else if (has_boxes) hipLaunchKernelGGL((k_render<false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);

@@ -53,7 +53,9 @@ __device__ inline bool near_grid_boundary(const DevScene& s, V3 pos, float thres
 #ifndef RT_RENDER_WAVES
 #define RT_RENDER_WAVES 1
 #endif
-template <bool WGSL, bool BOXES, bool TEX = false, bool WIDE = false>
+// SINGLE: max_bounces == 1 (direct lighting only): no bounce loop, so the ray origin stays the camera position in
+// scalar registers and nothing is carried from one traversal to the next.
+template <bool WGSL, bool BOXES, bool TEX = false, bool WIDE = false, bool SINGLE = false>
 __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(DevScene s, DevFrames fs, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
                                                 unsigned long long* stats) {
     const DevFrame& f = fs.f[blockIdx.y];
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(DevScene s, Dev
         V3 acc = v3(0.0f, 0.0f, 0.0f);
         float mult = 1.0f;
         const V3 to_light = f.shadow.d;  // -normalize(LIGHT_DIRECTION)
-        for (uint32_t bounce = 0; bounce < sh.max_bounces; ++bounce) {
+        for (uint32_t bounce = 0; bounce < (SINGLE ? 1u : sh.max_bounces); ++bounce) {
             const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
             HitRec h;
             counts += 1u;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(DevScene s, Dev
             if (show_grid > 0.5f && near_grid_boundary(s, pos, 0.02f)) lit = mix(lit, v3(0.0f, 1.0f, 0.0f), 0.6f);
             // bounce loop (:670-688)
             acc = acc + (lit * (1.0f - refl)) * mult;
-            if (refl < 0.01f) break;
+            if (SINGLE || refl < 0.01f) break;
             mult *= refl;
             d = d - n * (2.0f * dot(n, d));  // reflect(e1, e2) = e1 - 2 * dot(e2, e1) * e2
             o = pos + n * 0.001f;

@@ -96,6 +96,37 @@ def massive(core, sizes):
             log(f"massive n={n} {label}: build {build2_ms:.2f} ms trace {ms:.3f} ms {st['rays'] / ms / 1e3:.0f} Mrays/s")
 
 
+def unique(core, sizes):
+    """Scenes too large for the caches: n distinct small random triangles in the massive scene's volume (no copies,
+    so nothing is left out), grid cells sized for about eight references each, 3840x2160 primary + shadow."""
+    w, h = 3840, 2160
+    cam = rt.Camera((0, 0, 150), math.pi, 0.0).to_uniform(0.0, float(h))
+    rng = np.random.default_rng(1)
+    for n in sizes:
+        size = 100.0 / n ** (1.0 / 3.0)  # mean spacing
+        c = rng.uniform(-50, 50, (n, 1, 3)).astype(np.float32)
+        v = (c + rng.normal(0, 0.6 * size, (n, 3, 3)).astype(np.float32)).astype(np.float32)
+        tris = rt.triangles_from_xyz9(v.reshape(-1, 9))
+        del c, v
+        core.set_scene(None, tris)
+        cell = 2.0 * size
+        t0 = time.perf_counter()
+        meta, n_cells, n_refs = core.build_grid(cell_size=cell)
+        build_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        core.build_grid(cell_size=cell)
+        build2_ms = (time.perf_counter() - t0) * 1e3
+        p = rt.default_params(max_dda_steps=4096)
+        st = frame_stats(core, cam, w, h)
+        ms = timed(core, lambda: core.trace_primary(cam, w, h, out_primary=P[: w * h], out_shadow=S[: w * h]), 5)
+        alg = 8 * st["cells_visited"] + 40 * st["tri_tests"] + 8 * st["rays"]
+        emit(config="distinct random triangles 3840x2160 primary+shadow", triangles=n, cell_size=cell, dims=list(meta.fine_dims),
+             cells=n_cells, refs=n_refs, trace_refs=core.trace_refs(), record_bytes=48 * core.trace_refs(), build_ms_first=build_ms,
+             build_ms=build2_ms, trace_ms=ms, rays=st["rays"], primary_hits=st["primary_hits"], Mrays_per_s=st["rays"] / ms / 1e3,
+             cells_visited=st["cells_visited"], tri_tests=st["tri_tests"], algorithmic_GBps=alg / ms / 1e6)
+        log(f"unique n={n}: build {build2_ms:.2f} ms trace {ms:.3f} ms {st['rays'] / ms / 1e3:.0f} Mrays/s")
+
+
 def rays(core, sizes):
     """The example's own measurement: generate_test_rays through the structure (examples/massive_benchmark.rs:90-98)."""
     for n in sizes:
@@ -258,6 +289,8 @@ if __name__ == "__main__":
         bvh(core)
     if "rays" in what:
         rays(core, (100000, 1000000))
+    if "unique" in what:
+        unique(core, (1000000, 10000000, 40000000) if big else (1000000, 10000000))
     if "massive" in what:
         massive(core, (10000000,) if big else (100000, 1000000))
     core.close()

@@ -126,6 +126,14 @@ __device__ inline uint2 buf_load8(v4i rsrc, uint32_t index) {
     return make_uint2((uint32_t)v.x, (uint32_t)v.y);
 }
 
+// Per-wave LDS buffer for a cell list's reference records (see "LDS staging" in trace_ray): one array per kernel,
+// shared by every inlined traversal; kernels run at most four waves per workgroup.
+constexpr uint32_t STAGE_RECORDS = 64;
+__device__ inline float4* wave_stage() {
+    __shared__ float4 staged[4][3 * STAGE_RECORDS];
+    return staged[(threadIdx.x >> 6) & 3];
+}
+
 // One ray through the grid; mirrors raytracer_unified.wgsl:430-588.
 //
 // Per-wave cost on gfx950 is set by instruction issue and by the length of the dependent chain of the
@@ -136,6 +144,7 @@ __device__ inline uint2 buf_load8(v4i rsrc, uint32_t index) {
 //     rebuilding and range-checking cell coordinates,
 //   - "have a hit" is best_id != MISS, not a separate flag,
 //   - a candidate's 48-byte record is loaded while the previous candidate is tested (loop unrolled by two),
+//   - a cell list that the whole wave scans together is staged in LDS once (see scan below),
 //   - SKIP: a candidate that the ray already tested in the cell it just left is not tested again. The shader
 //     re-tests it, gets the same t, and that t can neither beat the closest hit under its strict '<' nor turn
 //     a rejection into a hit, so skipping changes nothing. The per-reference mask in q1.w says through which
@@ -277,6 +286,39 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     // flight never has to be copied into the registers of the record under test. The load one past the list
     // stays inside the array (padded by one record) and its result is not used.
     auto scan = [&](uint32_t r, uint32_t n) {
+        if constexpr (X != 2) {
+            // LDS staging. When every active lane of the wave is about to scan the SAME cell list (rays of an 8x8
+            // pixel block mostly are in the same cell), the wave copies the list's records into LDS once - each
+            // active lane fetches every n_active-th record - and all lanes read their candidates from there (same
+            // address in all lanes: a broadcast read, no bank conflicts) instead of issuing the same three 16-byte
+            // loads 64 times over. Order of the tests and their operands are unchanged. (X == 2: development build
+            // without it, for comparison.)
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r), n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+            const bool uniform = __builtin_amdgcn_ballot_w64(r == r0 && n == n0) == act;
+            if (uniform) {
+                float4* mine = wave_stage();
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                const uint32_t n_act = (uint32_t)__popcll(act);
+                bool done = false;  // any-hit: this lane has accepted a candidate
+                for (uint32_t base = 0; base < n0; base += STAGE_RECORDS) {  // lists longer than the buffer: in pieces
+                    const uint32_t cnt = n0 - base < STAGE_RECORDS ? n0 - base : STAGE_RECORDS;
+                    for (uint32_t k = rank; k < cnt; k += n_act) {
+                        mine[3 * k] = ref_quad(r0 + base + k, Q0{});
+                        mine[3 * k + 1] = ref_quad(r0 + base + k, Q1{});
+                        mine[3 * k + 2] = ref_quad(r0 + base + k, Q2{});
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (uint32_t k = 0; k < cnt && !done; ++k)
+                        done = test(mine[3 * k], mine[3 * k + 1], mine[3 * k + 2], r0 + base + k);
+                    __builtin_amdgcn_wave_barrier();  // the next piece may overwrite the buffer only after every lane is done
+                    if (ANY && __builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+                }
+                return;
+            }
+        }
         const uint32_t r_end = r + n;
         float4 a0 = ref_quad(r, Q0{}), a1 = ref_quad(r, Q1{}), a2 = ref_quad(r, Q2{});
         for (;;) {

@@ -3,7 +3,7 @@
 //
 // VARIANT v = launch shape * 10 + body:
 //   body 0      the shipped trace_ray
-//   body 1..9   trace_ray_x<body> below (whatever is being tried)
+//   body 1..9   trace_ray_x<body> below (whatever is being tried); body 2 = trace_ray without LDS staging
 //   0x          four waves per workgroup (shipped)      1x  one wave per workgroup
 //   2x          __launch_bounds__(256, 8)               3x  per-wave start/end timestamps into g_wave_t
 //   4x          persistent waves: 2048 workgroups (every wave slot of the chip once), each wave takes the next 8x8

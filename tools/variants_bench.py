@@ -17,9 +17,13 @@ variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0
 rounds, steps = 7, 50
 W, H = 1920, 1080
 core = rt.TraceCore(0)
-core.set_scene(None, rt.triangles_from_xyz9(np.load(os.path.join(ROOT, "tests/golden/car_tris.npy"))))
+if os.environ.get("RT_MODEL") == "phoenix":  # the animated model's bind pose, the camera of tools/bench_configs.py
+    core.set_scene(None, rt.triangles_from_xyz9(np.load(os.path.join(ROOT, "tests/golden/phoenix_tris.npy"))))
+    cam = rt.Camera((-300, 250, 600), 2.7, -0.2).to_uniform(0.0, float(H))
+else:
+    core.set_scene(None, rt.triangles_from_xyz9(np.load(os.path.join(ROOT, "tests/golden/car_tris.npy"))))
+    cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
 core.build_grid()
-cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
 p = torch.empty((W * H, 2), dtype=torch.int32, device="cuda")
 s = torch.empty_like(p)
 os.environ.pop("RT_VARIANT", None)

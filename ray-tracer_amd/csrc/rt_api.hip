@@ -38,58 +38,6 @@ __global__ void k_emit_cells(const uint32_t* __restrict__ cell_start, uint32_t g
     cells[p] = rec;
 }
 
-// The id word and the material word of every triangle reference, given the materials. A triangle whose material
-// discards all of its hits (constant alpha below the MASK cutoff / the BLEND threshold, no base-colour texture,
-// raytracer_unified.wgsl:291-316) keeps its record (the shader tests it) but can never be accepted. A triangle
-// whose alpha comes from a base-colour texture carries material + 1 in the spare word of its third quad: the
-// trace evaluates the rule per hit.
-__global__ void k_ref_visibility(const uint32_t* __restrict__ indices, uint32_t n_refs, uint32_t nb, uint32_t nt,
-                                 const uint32_t* __restrict__ tri_mat, const float4* __restrict__ materials,
-                                 uint32_t n_materials, float4* __restrict__ refs) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_refs) return;
-    const uint32_t id = indices[r];
-    if (id < nb || id - nb >= nt) return;
-    uint32_t word = id, mat_word = 0;
-    const uint32_t mat = tri_mat[id - nb];
-    if (mat < n_materials) {
-        const float4 m0 = materials[4 * mat], m1 = materials[4 * mat + 1], m3 = materials[4 * mat + 3];
-        const int texture = (int)__float_as_uint(m1.w);
-        const uint32_t mode = __float_as_uint(m3.x);
-        if (texture < 0) {
-            if ((mode == 1u && m0.w < m3.y) || (mode == 2u && m0.w < 0.01f)) word = REF_INVISIBLE;
-        } else if (mode == 1u || mode == 2u) {
-            mat_word = mat + 1u;
-        }
-    }
-    refs[3 * (size_t)r].w = __uint_as_float(word);
-    refs[3 * (size_t)r + 2].w = __uint_as_float(mat_word);
-}
-
-// One 48-byte record per reference, in cell order.
-__global__ void k_emit_refs(const uint32_t* __restrict__ indices, uint32_t n_refs, const float* __restrict__ tri_v,
-                            uint32_t nb, uint32_t nt, float4* __restrict__ refs) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_refs) return;
-    uint32_t id = indices[r];
-    float4 q0 = make_float4(0.f, 0.f, 0.f, __uint_as_float(id)), q1 = make_float4(0.f, 0.f, 0.f, 0.f), q2 = q1;
-    if (id >= nb) {
-        uint32_t ti = id - nb;
-        if (ti < nt) {
-            const float* v = tri_v + 9 * (size_t)ti;
-            V3 v0 = ld3(v), e1 = ld3(v + 3) - v0, e2 = ld3(v + 6) - v0;
-            q0 = make_float4(v0.x, v0.y, v0.z, __uint_as_float(id));
-            q1 = make_float4(e1.x, e1.y, e1.z, 0.f);
-            q2 = make_float4(e2.x, e2.y, e2.z, 0.f);
-        } else {
-            q0.w = __uint_as_float(REF_INVALID);
-        }
-    }
-    refs[3 * (size_t)r] = q0;
-    refs[3 * (size_t)r + 1] = q1;
-    refs[3 * (size_t)r + 2] = q2;
-}
-
 // reference: raytracer_unified.wgsl:147-155
 __device__ inline bool lod_culled(V3 cam, V3 center, V3 size, float lod_factor, float min_pixel_size) {
     float distance = length(cam - center);
@@ -445,16 +393,8 @@ int stage_in(rt_ctx* c, DevBuf& buf, const void* src, size_t bytes, const void**
 
 namespace rt {
 
-int apply_visibility(rt_ctx* c) {
-    if (!c->n_refs_t || !c->nt) return RT_OK;
-    hipLaunchKernelGGL(k_ref_visibility, dim3((c->n_refs_t + 255) / 256), dim3(256), 0, c->stream, c->t_indices,
-                       c->n_refs_t, c->grid_nb, c->nt, c->tri_mat.as<uint32_t>(), c->materials.as<float4>(), c->n_materials,
-                       c->refs.as<float4>());
-    RT_HIP(c, hipGetLastError());
-    return RT_OK;
-}
-
-int emit_refs_from_csr(rt_ctx* c) {
+// (first, count) records of the bordered cell array from the trace lists; reserves the reference records.
+int emit_cells(rt_ctx* c) {
     const uint32_t* g = c->meta.grid_sizes[RT_GRID_LEVELS - 1];
     const unsigned long long bordered = (g[0] + 2ull) * (g[1] + 2ull) * (g[2] + 2ull);
     if (bordered > 0xFFFFFFFFull)
@@ -465,13 +405,7 @@ int emit_refs_from_csr(rt_ctx* c) {
     hipLaunchKernelGGL(k_emit_cells, dim3((unsigned)((bordered + 255) / 256)), dim3(256), 0, c->stream,
                        c->t_cell_start, g[0], g[1], g[2], c->cells.as<uint2>());
     RT_HIP(c, hipGetLastError());
-    if (c->n_refs_t) {
-        hipLaunchKernelGGL(k_emit_refs, dim3((c->n_refs_t + 255) / 256), dim3(256), 0, c->stream,
-                           c->t_indices, c->n_refs_t, c->tri_v.as<float>(), c->grid_nb, c->nt,
-                           c->refs.as<float4>());
-        RT_HIP(c, hipGetLastError());
-    }
-    return apply_visibility(c);
+    return RT_OK;
 }
 
 }  // namespace rt
@@ -557,7 +491,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
                       &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->b_obj_n, &c->b_obj_off, &c->b_obj_sum, &c->out_p,     &c->out_s,
                       &c->in_o,      &c->in_d,      &c->stats,      &c->misc,      &c->tri_uv,    &c->texels,    &c->tc_start,  &c->tc_indices, &c->tc_pos, &c->dd_keys, &c->dd_keys2,
-                      &c->dd_vals, &c->dd_vals2, &c->dd_flag, &c->dd_head, &c->dd_dup};
+                      &c->dd_vals, &c->dd_vals2, &c->dd_flag, &c->dd_head, &c->dd_dup, &c->ref_cell, &c->tc_ref_cell};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1042,8 +976,8 @@ extern "C" int rt_set_materials(rt_ctx* c, const MaterialData* materials, uint32
             c->tex_mode = 1;
     }
     if (c->has_grid) {
-        // which duplicates may be left out depends on the materials; otherwise only the id / material words change
-        if (int r = c->grid_built && c->params.skip_duplicate_triangles ? rebuild_trace_records(c) : apply_visibility(c)) return r;
+        // which duplicates may be left out, and the id / material words of the records, depend on the materials
+        if (int r = rebuild_trace_records(c)) return r;
     }
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;

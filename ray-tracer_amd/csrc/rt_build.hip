@@ -138,9 +138,23 @@ __global__ __launch_bounds__(256) void k_bin(BinGrid g, const BoxData* __restric
                                              uint32_t* __restrict__ counts, const uint32_t* __restrict__ tmp_start,
                                              uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_cell) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    // object of a pair: last id with obj_off[id] <= p (objects without cells share their successor's offset).
+    // Two lanes search the whole table for the workgroup's first and last pair; everyone else searches between
+    // those two objects only (a few steps, from cache, instead of log2(objects) dependent loads per pair).
+    __shared__ uint32_t window[2];
+    if (threadIdx.x < 2) {
+        const uint32_t last = n_pairs - 1;
+        const uint32_t q = threadIdx.x == 0 ? blockIdx.x * blockDim.x : min(blockIdx.x * blockDim.x + blockDim.x - 1, last);
+        uint32_t lo = 0, hi = g.nb + g.nt;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (obj_off[mid] <= q) lo = mid; else hi = mid;
+        }
+        window[threadIdx.x] = lo;
+    }
+    __syncthreads();
     if (p >= n_pairs) return;
-    // object of this pair: last id with obj_off[id] <= p (objects without cells share their successor's offset)
-    uint32_t lo = 0, hi = g.nb + g.nt;
+    uint32_t lo = window[0], hi = window[1] + 1;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) / 2;
         if (obj_off[mid] <= p) lo = mid; else hi = mid;
@@ -161,45 +175,85 @@ __global__ __launch_bounds__(256) void k_bin(BinGrid g, const BoxData* __restric
     }
 }
 
-// Re-test masks. A reference (cell C, object T) gets bit 2a (2a+1) set when the cell one step back along axis a
-// in the - (+) direction also lists T and lists it within the part of its list that is traversed. A ray that
-// ENTERS C through that face has therefore just tested T against the same ray: testing it again would give the
-// same t, which can neither beat the current closest hit (strict <) nor turn a rejection into a hit, so the
-// trace kernel skips it. T's cells form a box and a line crosses a box in one run of face-adjacent cells, so
-// "listed one step back" is the same as "already tested". Cells whose lists may have been cut by the per-cell
-// cap never vouch for their neighbours (their bits stay 0), which keeps the skip exact.
-// cell_start / indices: the lists the records were made from; full_start: the reference's lists (whether a cell
-// was cut by the cap is a property of those).
-__global__ void k_ref_masks(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
-                            const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ indices,
-                            const uint32_t* __restrict__ full_start, uint32_t n_refs, uint32_t n_cells, uint32_t cap,
-                            float4* __restrict__ refs) {
+// One 48-byte record per reference, in cell order: geometry, id word, material word, re-test mask.
+//
+// Id and material words (raytracer_unified.wgsl:291-316): a triangle whose material discards all of its hits
+// (constant alpha below the MASK cutoff / the BLEND threshold, no base-colour texture) keeps its record - the shader
+// tests it - but can never be accepted: REF_INVISIBLE. A triangle whose alpha comes from a base-colour texture carries
+// material + 1 in the spare word of its third quad: the trace evaluates the rule per hit.
+//
+// Re-test masks (grids built here: ref_cell != nullptr). A reference (cell C, object T) gets bit 2a (2a+1) set when
+// the cell one step back along axis a in the - (+) direction also lists T and lists it within the part of its list
+// that is traversed. A ray that ENTERS C through that face has therefore just tested T against the same ray: testing
+// it again would give the same t, which can neither beat the current closest hit (strict <) nor turn a rejection into
+// a hit, so the trace kernel skips it. T's cells form a box and a line crosses a box in one run of face-adjacent
+// cells, so "listed one step back" is the same as "already tested". Cells whose lists may have been cut by the
+// per-cell cap never vouch for their neighbours (their bits stay 0), which keeps the skip exact. full_start: the
+// reference's lists (whether a cell was cut by the cap is a property of those, not of lists with copies left out).
+__global__ void k_emit_records(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                               const uint32_t* __restrict__ indices, const uint32_t* __restrict__ ref_cell,
+                               const uint32_t* __restrict__ full_start, uint32_t n_refs, uint32_t cap,
+                               const uint32_t* __restrict__ tri_mat, const float4* __restrict__ materials, uint32_t n_materials,
+                               float4* __restrict__ refs) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_refs) return;
-    // cell of this reference: last c with cell_start[c] <= r
-    uint32_t lo = 0, hi = n_cells;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) / 2;
-        if (cell_start[mid] <= r) lo = mid; else hi = mid;
-    }
-    const uint32_t c = lo;
-    const uint32_t cc[3] = {c % g.gx, (c / g.gx) % g.gy, c / (g.gx * g.gy)};
-    const uint32_t stride[3] = {1u, g.gx, g.gx * g.gy};
-    V3 mn, mx;
-    object_bounds(boxes, tri_v, g.nb, indices[r], mn, mx);
-    const Range3 rg = cell_range(g, mn, mx);
-    uint32_t mask = 0;
-    for (int a = 0; a < 3; ++a) {
-        if ((int)cc[a] > rg.lo[a]) {  // arrived by a + step: previous cell is c - stride
-            const uint32_t p = c - stride[a];
-            if (full_start[p + 1] - full_start[p] < cap) mask |= 1u << (2 * a);
+    const uint32_t id = indices[r];
+    uint32_t word = id, mat_word = 0, mask = 0;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    V3 mn = v3(0.f, 0.f, 0.f), mx = mn;
+    bool known = true;
+    if (id >= g.nb) {
+        const uint32_t ti = id - g.nb;
+        if (ti < g.nt) {
+            const float* v = tri_v + 9 * (size_t)ti;
+            const V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+            const V3 e1 = v1 - v0, e2 = v2 - v0;
+            q0 = make_float4(v0.x, v0.y, v0.z, 0.f);
+            q1 = make_float4(e1.x, e1.y, e1.z, 0.f);
+            q2 = make_float4(e2.x, e2.y, e2.z, 0.f);
+            mn = vmin(vmin(v0, v1), v2);
+            mx = vmax(vmax(v0, v1), v2);
+            const uint32_t mat = tri_mat[ti];
+            if (mat < n_materials) {
+                const float4 m0 = materials[4 * mat], m1 = materials[4 * mat + 1], m3 = materials[4 * mat + 3];
+                const int texture = (int)__float_as_uint(m1.w);
+                const uint32_t mode = __float_as_uint(m3.x);
+                if (texture < 0) {
+                    if ((mode == 1u && m0.w < m3.y) || (mode == 2u && m0.w < 0.01f)) word = REF_INVISIBLE;
+                } else if (mode == 1u || mode == 2u) {
+                    mat_word = mat + 1u;
+                }
+            }
+        } else {
+            word = REF_INVALID;
+            known = false;
         }
-        if ((int)cc[a] < rg.hi[a]) {  // arrived by a - step: previous cell is c + stride
-            const uint32_t p = c + stride[a];
-            if (full_start[p + 1] - full_start[p] < cap) mask |= 2u << (2 * a);
+    } else {
+        mn = ld3(boxes[id].min);
+        mx = ld3(boxes[id].max);
+    }
+    if (ref_cell && known) {
+        const uint32_t c = ref_cell[r];
+        const uint32_t cc[3] = {c % g.gx, (c / g.gx) % g.gy, c / (g.gx * g.gy)};
+        const uint32_t stride[3] = {1u, g.gx, g.gx * g.gy};
+        const Range3 rg = cell_range(g, mn, mx);
+        for (int a = 0; a < 3; ++a) {
+            if ((int)cc[a] > rg.lo[a]) {  // arrived by a + step: previous cell is c - stride
+                const uint32_t p = c - stride[a];
+                if (full_start[p + 1] - full_start[p] < cap) mask |= 1u << (2 * a);
+            }
+            if ((int)cc[a] < rg.hi[a]) {  // arrived by a - step: previous cell is c + stride
+                const uint32_t p = c + stride[a];
+                if (full_start[p + 1] - full_start[p] < cap) mask |= 2u << (2 * a);
+            }
         }
     }
-    refs[3 * (size_t)r + 1].w = __uint_as_float(mask);
+    q0.w = __uint_as_float(word);
+    q1.w = __uint_as_float(mask);
+    q2.w = __uint_as_float(mat_word);
+    refs[3 * (size_t)r] = q0;
+    refs[3 * (size_t)r + 1] = q1;
+    refs[3 * (size_t)r + 2] = q2;
 }
 
 __global__ void k_clamp_counts(const uint32_t* __restrict__ counts, uint32_t n_cells, uint32_t cap,
@@ -211,12 +265,15 @@ __global__ void k_clamp_counts(const uint32_t* __restrict__ counts, uint32_t n_c
 
 __global__ void k_compact(const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ tmp_cell,
                           const uint32_t* __restrict__ tmp_start, const uint32_t* __restrict__ final_start, uint32_t n_tmp,
-                          uint32_t cap, uint32_t* __restrict__ indices) {
+                          uint32_t cap, uint32_t* __restrict__ indices, uint32_t* __restrict__ ref_cell) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_tmp) return;
     const uint32_t c = tmp_cell[r];
     const uint32_t j = r - tmp_start[c];
-    if (j < cap) indices[final_start[c] + j] = sorted[r];
+    if (j < cap) {
+        indices[final_start[c] + j] = sorted[r];
+        ref_cell[final_start[c] + j] = c;
+    }
 }
 
 // ---- duplicate triangles -------------------------------------------------------------------------------
@@ -281,11 +338,15 @@ __global__ void k_keep_flags(const uint32_t* __restrict__ indices, uint32_t n_re
     keep[r] = v;  // entry n_refs closes the scan
 }
 
-__global__ void k_compact_refs(const uint32_t* __restrict__ indices, const uint32_t* __restrict__ pos, uint32_t n_refs,
-                               uint32_t* __restrict__ out) {
+__global__ void k_compact_refs(const uint32_t* __restrict__ indices, const uint32_t* __restrict__ ref_cell,
+                               const uint32_t* __restrict__ pos, uint32_t n_refs, uint32_t* __restrict__ out,
+                               uint32_t* __restrict__ out_cell) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_refs) return;
-    if (pos[r + 1] != pos[r]) out[pos[r]] = indices[r];
+    if (pos[r + 1] != pos[r]) {
+        out[pos[r]] = indices[r];
+        out_cell[pos[r]] = ref_cell[r];
+    }
 }
 
 __global__ void k_compact_starts(const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ pos, uint32_t n_cells,
@@ -302,6 +363,7 @@ int rebuild_trace_records(rt_ctx* c) {
     hipStream_t st = c->stream;
     c->t_cell_start = c->cell_start.as<uint32_t>();
     c->t_indices = c->indices.as<uint32_t>();
+    c->t_ref_cell = c->grid_built ? c->ref_cell.as<uint32_t>() : nullptr;
     c->n_refs_t = c->n_refs;
     const uint32_t nb = c->grid_nb, nt = c->nt, n_refs = c->n_refs, n_cells = c->n_cells;
     // Only for lists this library built (lowest ids survive the cap), when the shader's own cap does not cut them
@@ -351,19 +413,22 @@ int rebuild_trace_records(rt_ctx* c) {
         c->dup_state = kept < n_refs ? 1 : 0;
         if (kept < n_refs) {
             RT_HIP(c, c->tc_indices.reserve((size_t)kept * 4 + 16));
+            RT_HIP(c, c->tc_ref_cell.reserve((size_t)kept * 4 + 16));
             RT_HIP(c, c->tc_start.reserve(((size_t)n_cells + 1) * 4));
             hipLaunchKernelGGL(k_compact_refs, dim3((n_refs + 255) / 256), dim3(256), 0, st, c->indices.as<uint32_t>(),
-                               (const uint32_t*)pos, n_refs, c->tc_indices.as<uint32_t>());
+                               (const uint32_t*)c->ref_cell.as<uint32_t>(), (const uint32_t*)pos, n_refs,
+                               c->tc_indices.as<uint32_t>(), c->tc_ref_cell.as<uint32_t>());
             hipLaunchKernelGGL(k_compact_starts, dim3((n_cells + 1 + 255) / 256), dim3(256), 0, st, c->cell_start.as<uint32_t>(),
                                (const uint32_t*)pos, n_cells, c->tc_start.as<uint32_t>());
             RT_HIP(c, hipGetLastError());
             c->t_cell_start = c->tc_start.as<uint32_t>();
             c->t_indices = c->tc_indices.as<uint32_t>();
+            c->t_ref_cell = c->tc_ref_cell.as<uint32_t>();
             c->n_refs_t = kept;
         }
     }
-    if (int r = emit_refs_from_csr(c)) return r;
-    if (c->grid_built && c->n_refs_t) {
+    if (int r = emit_cells(c)) return r;
+    if (c->n_refs_t) {
         BinGrid g;
         g.bmin[0] = c->meta.bounds_min[0], g.bmin[1] = c->meta.bounds_min[1], g.bmin[2] = c->meta.bounds_min[2];
         g.cell = c->meta.finest_cell_size;
@@ -373,9 +438,10 @@ int rebuild_trace_records(rt_ctx* c) {
         g.nb = nb, g.nt = nt;
         g.tri_mode = c->grid_mode == RT_GRID_TRIANGLES ? 1 : 0;
         const uint32_t cap = std::min(c->build_cap, c->params.max_objects_per_cell);
-        hipLaunchKernelGGL(k_ref_masks, dim3((c->n_refs_t + 255) / 256), dim3(256), 0, st, g, c->boxes.as<BoxData>(),
-                           c->tri_v.as<float>(), c->t_cell_start, c->t_indices, (const uint32_t*)c->cell_start.as<uint32_t>(),
-                           c->n_refs_t, n_cells, cap, c->refs.as<float4>());
+        hipLaunchKernelGGL(k_emit_records, dim3((c->n_refs_t + 255) / 256), dim3(256), 0, st, g, c->boxes.as<BoxData>(),
+                           c->tri_v.as<float>(), c->t_indices, c->t_ref_cell, (const uint32_t*)c->cell_start.as<uint32_t>(),
+                           c->n_refs_t, cap, c->tri_mat.as<uint32_t>(), c->materials.as<float4>(), c->n_materials,
+                           c->refs.as<float4>());
         RT_HIP(c, hipGetLastError());
     }
     return RT_OK;
@@ -555,9 +621,10 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
         RT_HIP(c, hipMemcpyAsync(&n_refs, final_start + n_cells, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         RT_HIP(c, hipStreamSynchronize(st));
         RT_HIP(c, c->indices.reserve((size_t)n_refs * sizeof(uint32_t) + 16));
+        RT_HIP(c, c->ref_cell.reserve((size_t)n_refs * sizeof(uint32_t) + 16));
         hipLaunchKernelGGL(k_compact, dim3((n_tmp + 255) / 256), dim3(256), 0, st, (const uint32_t*)tmp_sorted,
                            (const uint32_t*)tmp_cell, (const uint32_t*)tmp_start, (const uint32_t*)final_start, n_tmp,
-                           max_per_cell, c->indices.as<uint32_t>());
+                           max_per_cell, c->indices.as<uint32_t>(), c->ref_cell.as<uint32_t>());
         RT_HIP(c, hipGetLastError());
     } else {
         RT_HIP(c, hipMemsetAsync(final_start, 0, cell_bytes, st));

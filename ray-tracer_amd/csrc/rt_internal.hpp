@@ -95,6 +95,8 @@ struct rt_ctx {
     int dup_state = -1;
     const uint32_t* t_cell_start = nullptr;  // = cell_start or tc_start
     const uint32_t* t_indices = nullptr;     // = indices or tc_indices
+    const uint32_t* t_ref_cell = nullptr;    // cell of every entry of t_indices (grids built here only)
+    rt::DevBuf ref_cell, tc_ref_cell;
     rt::DevBuf tc_start, tc_indices, tc_pos, dd_keys, dd_keys2, dd_vals, dd_vals2, dd_flag, dd_head, dd_dup;
     rt::DevBuf cells;       // uint2[n_cells]
     rt::DevBuf refs;        // float4[3*n_refs]
@@ -148,12 +150,10 @@ inline bool is_device_ptr(const void* p) {
 
 // implemented in rt_build.hip
 int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode);
-// implemented in rt_api.hip: (t_cell_start, t_indices) on device -> cells + refs records
-int emit_refs_from_csr(rt_ctx* c);
+// implemented in rt_api.hip: t_cell_start on device -> bordered cell records; reserves the reference records
+int emit_cells(rt_ctx* c);
 // implemented in rt_build.hip: trace records (cells, refs, masks, visibility) from the current cell lists,
 // vertices and materials; leaves duplicate triangles out when the grid and the parameters allow it
 int rebuild_trace_records(rt_ctx* c);
-// implemented in rt_api.hip: rewrites the id word of triangle references from the current materials
-int apply_visibility(rt_ctx* c);
 
 }  // namespace rt

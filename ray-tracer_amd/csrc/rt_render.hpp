@@ -4,7 +4,7 @@
 // triangle material (:280-303, :345-364).
 //
 // The alpha MASK / BLEND rejection inside the triangle test (:303-316) happens in the trace: for materials with a
-// constant alpha it is folded into the reference records when materials are set (k_ref_visibility in rt_api.hip),
+// constant alpha it is folded into the reference records when materials are set (k_emit_records in rt_build.hip),
 // for a textured alpha trace_ray<TEX> samples per hit. TEX here: materials name textures, so the winning hit's
 // material is evaluated at its interpolated uv (base-colour texture, normal map, emissive texture: rt_texture.hpp).
 //

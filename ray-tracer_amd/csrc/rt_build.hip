@@ -130,13 +130,14 @@ __global__ __launch_bounds__(256) void k_obj_pairs(BinGrid g, const BoxData* __r
 
 // One lane per (object, cell) pair, so an object that spans thousands of cells (a ground plane) is spread over
 // thousands of lanes instead of one lane's loop. obj_off = exclusive scan of the per-object pair counts.
-// COUNT pass: counts[cell]++.  FILL pass: append the id to the cell's segment (order inside a cell is arbitrary
-// here, the per-cell sort that follows makes it ascending).
+// COUNT pass: slot = counts[cell]++, kept per pair.  FILL pass: the id goes to the cell's segment at that slot
+// (order inside a cell is arbitrary here, the per-cell sort that follows makes it ascending).
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
                                              const uint32_t* __restrict__ obj_off, uint32_t n_pairs,
-                                             uint32_t* __restrict__ counts, const uint32_t* __restrict__ tmp_start,
-                                             uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_cell) {
+                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ slots,
+                                             const uint32_t* __restrict__ tmp_start, uint32_t* __restrict__ tmp_ids,
+                                             uint32_t* __restrict__ tmp_cell) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     // object of a pair: last id with obj_off[id] <= p (objects without cells share their successor's offset).
     // Two lanes search the whole table for the workgroup's first and last pair; everyone else searches between
@@ -167,9 +168,10 @@ __global__ __launch_bounds__(256) void k_bin(BinGrid g, const BoxData* __restric
     const uint32_t j = p - obj_off[id];
     const uint32_t x = (uint32_t)r.lo[0] + j % nx, y = (uint32_t)r.lo[1] + (j / nx) % ny, z = (uint32_t)r.lo[2] + j / (nx * ny);
     const uint32_t c = x + y * g.gx + z * g.gx * g.gy;
-    const uint32_t slot = atomicAdd(&counts[c], 1u);
-    if (FILL) {
-        const uint32_t dst = tmp_start[c] + slot;
+    if (!FILL) {
+        slots[p] = atomicAdd(&counts[c], 1u);  // the pair's place inside its cell: the fill pass needs no atomics
+    } else {
+        const uint32_t dst = tmp_start[c] + slots[p];
         tmp_ids[dst] = id;
         tmp_cell[dst] = c;
     }
@@ -542,7 +544,6 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
     uint32_t* obj_n = c->b_obj_n.as<uint32_t>();
     uint32_t* obj_off = c->b_obj_off.as<uint32_t>();
     RT_HIP(c, hipMemsetAsync(counts, 0, cell_bytes, st));
-    RT_HIP(c, hipMemsetAsync(cursor, 0, cell_bytes, st));
     size_t scan_bytes = 0;
     unsigned long long n_pairs64 = 0;
     if (total) {
@@ -569,9 +570,10 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
     const uint32_t n_tmp = (uint32_t)n_pairs64;
     const dim3 pair_grid((n_tmp + 255) / 256);
     if (n_tmp) {
+        RT_HIP(c, c->b_flags.reserve((size_t)n_tmp * sizeof(uint32_t)));
         hipLaunchKernelGGL(k_bin<false>, pair_grid, dim3(256), 0, st, g, c->boxes.as<BoxData>(), c->tri_v.as<float>(),
-                           (const uint32_t*)obj_off, n_tmp, counts, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr);
+                           (const uint32_t*)obj_off, n_tmp, counts, c->b_flags.as<uint32_t>(), (const uint32_t*)nullptr,
+                           (uint32_t*)nullptr, (uint32_t*)nullptr);
         RT_HIP(c, hipGetLastError());
     }
 
@@ -592,7 +594,8 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
         uint32_t* tmp_sorted = c->b_tmp_sorted.as<uint32_t>();
         uint32_t* tmp_cell = c->b_tmp_cell.as<uint32_t>();
         hipLaunchKernelGGL(k_bin<true>, pair_grid, dim3(256), 0, st, g, c->boxes.as<BoxData>(), c->tri_v.as<float>(),
-                           (const uint32_t*)obj_off, n_tmp, cursor, (const uint32_t*)tmp_start, tmp_ids, tmp_cell);
+                           (const uint32_t*)obj_off, n_tmp, (uint32_t*)nullptr, c->b_flags.as<uint32_t>(),
+                           (const uint32_t*)tmp_start, tmp_ids, tmp_cell);
         RT_HIP(c, hipGetLastError());
         // rocPRIM's segmented sort launches work per segment and stops sorting (without an error) from about 2^25
         // segments on, so the cells go through it in batches; offsets stay absolute, so every batch addresses the

@@ -40,7 +40,9 @@ TILE = 32
 FRAMES_IN_FLIGHT = 2
 # At N > 1 a rank owns 1/N of the tiles but its slowest pixel block still is a ~100 us dependent chain, and every
 # frame also spends time on the links: more frames have to be in flight to keep the GPUs busy.
-GROUP = 16            # frames per launch / gather / assemble at N > 1
+# frames per launch / gather / assemble at N > 1 (8 and 16 measure alike on the GPU side; gloo, used to rehearse this
+# path on one GPU, stalls on the 64 MB tensors that 16 frames make at N = 2)
+GROUP = int(os.environ.get("RT_BENCH_GROUP", "8"))
 GROUPS_IN_FLIGHT = 3
 
 
@@ -114,6 +116,10 @@ def main():
     args = ap.parse_args()
 
     import torch.distributed as dist
+
+    if os.environ.get("RT_BENCH_WATCHDOG"):  # development: dump every thread's stack if the run takes this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
 
     import ray_tracer_amd as rt
     from ray_tracer_amd import sharding

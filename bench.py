@@ -11,7 +11,8 @@ flight): a frame's last waves - a few pixel blocks over the model's densest cell
 each - then overlap the next frame's bulk instead of leaving the GPU idle. At N > 1
 the SAME frame is cut into 64x64 tiles dealt round-robin to the ranks, each rank shades its tiles (same
 primary + shadow rays) and the RGBA8 framebuffer is gathered on rank 0 by RCCL (total work fixed: strong
-scaling; 4 bytes per pixel cross the links instead of 16 for hit records). A rank's share of one 1080p frame is
+scaling; 3 bytes per pixel cross the links - the picture without its constant alpha byte - instead of 16 for hit
+records). A rank's share of one 1080p frame is
 only ~10 us of GPU work, far less than one launch + one collective cost on the host, so at N > 1 the steps run as
 groups of GROUP consecutive frames: one launch renders the rank's tiles of the whole group, one gather moves them,
 one launch assembles them (a renderer running a camera path ahead of display); every frame is still traced,
@@ -43,7 +44,7 @@ FRAMES_IN_FLIGHT = 2
 # frames per launch / gather / assemble at N > 1 (8 and 16 measure alike on the GPU side; gloo, used to rehearse this
 # path on one GPU, stalls on the 64 MB tensors that 16 frames make at N = 2)
 GROUP = int(os.environ.get("RT_BENCH_GROUP", "8"))
-GROUPS_IN_FLIGHT = 3
+GROUPS_IN_FLIGHT = int(os.environ.get("RT_BENCH_GROUPS_IN_FLIGHT", "2"))
 
 
 def algorithmic_bytes(stats):
@@ -177,12 +178,24 @@ def main():
         # the framebuffer that travels is the shaded RGBA8 picture; one bounce = the same primary + shadow rays
         sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
                                    frames_in_flight=1, max_bounces=1)
-        sh.enable_groups(GROUP, GROUPS_IN_FLIGHT)
+        sh.enable_groups(GROUP, GROUPS_IN_FLIGHT, rgb8=os.environ.get("RT_BENCH_WIRE", "rgb") == "rgb")  # the constant alpha byte stays at home
+        if os.environ.get("RT_BENCH_TRACE"):  # development: where every rank is, every few seconds
+            import threading
+
+            def report():
+                while True:
+                    time.sleep(5)
+                    print(f"[rank {rank}] groups started {sh.group_no}, streams idle "
+                          f"{[sl.stream.query() for sl in sh.gslots]}", file=sys.stderr, flush=True)
+            threading.Thread(target=report, daemon=True).start()
         sh.trace_group([cam])  # set-up, untimed: the first collective creates the RCCL communicator
         sh.synchronize()
         pending = []
 
         def step():
+            if os.environ.get("RT_BENCH_PER_FRAME"):  # development: one launch, gather and assemble per frame
+                sh.trace(cam)
+                return
             pending.append(cam)
             if len(pending) == GROUP:
                 sh.trace_group(pending)
@@ -255,7 +268,7 @@ def main():
                        "frames_in_flight": FRAMES_IN_FLIGHT if world == 1 else GROUP * GROUPS_IN_FLIGHT,
                        "frames_per_launch_and_gather": 1 if world == 1 else GROUP,
                        "output": "rt_hit records, 16 B per pixel, resident in HBM" if world == 1 else
-                                 "shaded RGBA8 picture (ambient + diffuse with the shadow-ray term), 4 B per pixel, gathered on rank 0",
+                                 "shaded RGBA8 picture (ambient + diffuse with the shadow-ray term) assembled on rank 0; 3 B per pixel on the links (alpha is constant)",
                        "parallelism": "single GPU" if world == 1 else f"{TILE}x{TILE} tiles round-robin over {world} GPUs, RCCL gather to rank 0"},
         }
         if world == 1:

@@ -45,6 +45,8 @@ extern "C" {
     pub fn rt_set_textures(ctx: *mut RtCtx, textures: *const RtTexture, n: u32) -> c_int;
     pub fn rt_render_frames(ctx: *mut RtCtx, cameras: *const c_void, n_frames: u32, width: u32, height: u32,
                             shard: *const c_void, opts: *const c_void, out_rgba8: *mut u8) -> c_int;
+    pub fn rt_assemble_frames_rgb8(ctx: *mut RtCtx, gathered: *const u8, width: u32, height: u32, tile_w: u32, tile_h: u32,
+                                   n_ranks: u32, n_frames: u32, rank_stride: usize, frame_stride: usize, images: *mut u8) -> c_int;
     pub fn rt_assemble_frames_rgba8(ctx: *mut RtCtx, gathered: *const u8, width: u32, height: u32, tile_w: u32, tile_h: u32,
                                     n_ranks: u32, n_frames: u32, rank_stride: usize, frame_stride: usize, images: *mut u8) -> c_int;
     pub fn rt_set_skin(ctx: *mut RtCtx, positions: *const f32, joints: *const u16, weights: *const f32, n_vertices: u32,
@@ -63,7 +65,7 @@ extern "C" {
 /// `rt_render_opts` of include/rt_mi355.h.
 #[repr(C)]
 #[derive(Copy, Clone, Default)]
-pub struct RtRenderOpts { pub max_bounces: u32, pub shadows: u32, pub debug_enabled: u32, pub debug_pixel: [u32; 2], pub _pad: [u32; 3] }
+pub struct RtRenderOpts { pub max_bounces: u32, pub shadows: u32, pub debug_enabled: u32, pub debug_pixel: [u32; 2], pub pixel_format: u32, pub _pad: [u32; 2] }
 
 /// Owns one context. `Send` but not `Sync`: the C side is not re-entrant (one in-order stream).
 pub struct TraceCore { ctx: *mut RtCtx }

@@ -246,8 +246,14 @@ typedef struct rt_render_opts {
                                  rt_trace_primary) is occluded receives no diffuse light - not in the shader */
     uint32_t debug_enabled;   /* DebugParams (src/types.rs:187-193): highlight of the debug pixel, wgsl:693-716 */
     uint32_t debug_pixel[2];
-    uint32_t _pad[3];
+    uint32_t pixel_format;    /* RT_PIXEL_RGBA8 (0): 4 bytes per pixel, the shader's texture. RT_PIXEL_RGB8 (1): the same
+                                 picture without its constant alpha byte, 3 bytes per pixel - a quarter less to move
+                                 when the framebuffer is gathered from other GPUs (rt_assemble_frames_rgb8 puts the
+                                 alpha byte back); no reference counterpart */
+    uint32_t _pad[2];
 } rt_render_opts;
+#define RT_PIXEL_RGBA8 0u
+#define RT_PIXEL_RGB8 1u
 void rt_default_render_opts(rt_render_opts* o);
 
 /* Replaces the "Materials" storage buffer (src/renderer.rs:147-156): MaterialData records
@@ -303,6 +309,12 @@ int rt_assemble_tiles_rgba8(rt_ctx* ctx, const uint8_t* gathered, uint32_t width
 int rt_assemble_frames_rgba8(rt_ctx* ctx, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
                              uint32_t tile_h, uint32_t n_ranks, uint32_t n_frames, size_t rank_stride,
                              size_t frame_stride, uint8_t* images);
+
+/* The same for frames rendered with pixel_format = RT_PIXEL_RGB8: gathered holds 3-byte pixels (strides in
+ * pixels), images receives 4-byte RGBA8 pictures with alpha 255. No reference counterpart. */
+int rt_assemble_frames_rgb8(rt_ctx* ctx, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+                            uint32_t tile_h, uint32_t n_ranks, uint32_t n_frames, size_t rank_stride,
+                            size_t frame_stride, uint8_t* images);
 
 /* Counters of the most recent trace call made with params.collect_stats = 1. */
 int rt_get_stats(rt_ctx* ctx, rt_stats* stats);

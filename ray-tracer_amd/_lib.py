@@ -81,7 +81,7 @@ class RtTexture(C.Structure):
 
 class RtRenderOpts(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("shadows", C.c_uint32), ("debug_enabled", C.c_uint32),
-                ("debug_pixel", C.c_uint32 * 2), ("_pad", C.c_uint32 * 3)]
+                ("debug_pixel", C.c_uint32 * 2), ("pixel_format", C.c_uint32), ("_pad", C.c_uint32 * 2)]
 
 
 class RayDebugInfo(C.Structure):
@@ -122,6 +122,7 @@ PROTOTYPES = {
     "rt_read_vertices": (_I, [_VP, _VP]),
     "rt_assemble_tiles_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
     "rt_assemble_frames_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, C.c_size_t, C.c_size_t, _VP]),
+    "rt_assemble_frames_rgb8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, C.c_size_t, C.c_size_t, _VP]),
     "rt_render_frames": (_I, [_VP, _VP, _U32, _U32, _U32, C.POINTER(RtShard), C.POINTER(RtRenderOpts), _VP]),
     "rt_default_render_opts": (None, [C.POINTER(RtRenderOpts)]),
     "rt_set_materials": (_I, [_VP, _VP, _U32]),

@@ -890,6 +890,43 @@ extern "C" int rt_assemble_frames_rgba8(rt_ctx* c, const uint8_t* gathered, uint
                                     "rt_assemble_frames_rgba8", n_frames, frame_stride);
 }
 
+// 3-byte pixels in, 4-byte pixels (alpha 255) out.
+__global__ void k_assemble_rgb8(const uint8_t* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+                                uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks, size_t per_rank, size_t frame_stride,
+                                uint32_t* __restrict__ image) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    uint32_t tile = (y / tile_h) * tiles_x + (x / tile_w);
+    uint32_t rank = tile % n_ranks, lt = tile / n_ranks;
+    size_t src = (size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h +
+                 (size_t)(y % tile_h) * tile_w + (x % tile_w);
+    const uint8_t* p = gathered + 3 * src;
+    image[(size_t)blockIdx.z * width * height + (size_t)y * width + x] =
+        (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
+}
+
+extern "C" int rt_assemble_frames_rgb8(rt_ctx* c, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
+                                       uint32_t tile_h, uint32_t n_ranks, uint32_t n_frames, size_t rank_stride,
+                                       size_t frame_stride, uint8_t* images) {
+    const char* who = "rt_assemble_frames_rgb8";
+    if (int r = use(c)) return r;
+    if (!gathered || !images || !width || !height || !tile_w || !tile_h || !n_ranks)
+        return fail(c, RT_ERR_INVALID, "%s: NULL or zero argument", who);
+    if (!is_device_ptr(gathered) || !is_device_ptr(images))
+        return fail(c, RT_ERR_INVALID, "%s: both buffers must be device memory", who);
+    const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
+    const size_t min_stride = (size_t)((tiles_x * tiles_y + n_ranks - 1) / n_ranks) * tile_w * tile_h;
+    const size_t per_rank = rank_stride ? rank_stride : min_stride;
+    if (n_frames == 0) return RT_OK;
+    if (n_frames > 65535u) return fail(c, RT_ERR_LIMIT, "%s: more than 65535 frames", who);
+    if (per_rank < min_stride || (n_frames > 1 && (frame_stride < min_stride || per_rank < (size_t)n_frames * min_stride)))
+        return fail(c, RT_ERR_INVALID, "%s: frame_stride / rank_stride smaller than the frames they hold", who);
+    hipLaunchKernelGGL(k_assemble_rgb8, dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream, gathered, width,
+                       height, tile_w, tile_h, tiles_x, n_ranks, per_rank, frame_stride, reinterpret_cast<uint32_t*>(images));
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
 // ================================================================== skinning
 
 extern "C" int rt_set_skin(rt_ctx* c, const float* positions, const uint16_t* joints, const float* weights, uint32_t n_vertices,
@@ -1037,10 +1074,13 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
     if (n_out == 0) return RT_OK;
     const uint64_t blocks = (uint64_t)m.n_local * ((m.sub_x + 1) / 2) * ((m.sub_y + 1) / 2);
     if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "rt_render: frame too large");
+    if (o.pixel_format != RT_PIXEL_RGBA8 && o.pixel_format != RT_PIXEL_RGB8)
+        return fail(c, RT_ERR_INVALID, "rt_render: unknown pixel_format %u", o.pixel_format);
+    const size_t out_bytes = n_out * (o.pixel_format == RT_PIXEL_RGB8 ? 3 : 4);
     const bool host_out = !is_device_ptr(out_rgba8);
     uint32_t* out = reinterpret_cast<uint32_t*>(out_rgba8);
     if (host_out) {
-        RT_HIP(c, c->out_p.reserve(n_out * sizeof(uint32_t)));
+        RT_HIP(c, c->out_p.reserve(out_bytes + 16));
         out = c->out_p.as<uint32_t>();
     }
     if (int r = update_box_frames(c, cams, n_frames)) return r;
@@ -1065,6 +1105,7 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
     sh.debug_enabled = o.debug_enabled;
     sh.debug_x = o.debug_pixel[0];
     sh.debug_y = o.debug_pixel[1];
+    sh.rgb8 = o.pixel_format == RT_PIXEL_RGB8 ? 1u : 0u;
     sh.box_frame_stride = c->nb * 4;
     sh.frame_pixels = n_frame;
     unsigned long long* st = stats ? c->stats.as<unsigned long long>() : nullptr;
@@ -1086,7 +1127,7 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
     else if (has_boxes) hipLaunchKernelGGL((k_render<false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
     else hipLaunchKernelGGL((k_render<false, false>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
     RT_HIP(c, hipGetLastError());
-    if (host_out) RT_HIP(c, hipMemcpyAsync(out_rgba8, out, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (host_out) RT_HIP(c, hipMemcpyAsync(out_rgba8, out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     if (stats) {
         if (int r = fetch_stats(c)) return r;
     } else if (host_out) {

@@ -24,6 +24,7 @@ struct DevShade {
     uint32_t max_bounces;
     uint32_t shadows;         // 1: a hit whose shadow ray is occluded gets no diffuse light (not in the shader)
     uint32_t debug_enabled, debug_x, debug_y;
+    uint32_t rgb8;              // 1: 3-byte pixels (no alpha byte)
     uint32_t box_frame_stride;  // float4 records between the per-frame box records of consecutive frames
     size_t frame_pixels;        // output records per frame
 };
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(DevScene s, Dev
     const DevFrame& f = fs.f[blockIdx.y];
     const float show_grid = fs.show_grid[blockIdx.y];
     s.box_frame += (size_t)blockIdx.y * sh.box_frame_stride;
-    out += (size_t)blockIdx.y * sh.frame_pixels;
+    const size_t frame_first = (size_t)blockIdx.y * sh.frame_pixels;
     const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
     const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;
     const uint32_t blk_per_tile = blk_x * blk_y;
@@ -162,7 +163,15 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(DevScene s, Dev
         }
         rgba = unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xFF000000u;
     }
-    if (in_tile) out[(size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx] = rgba;
+    if (in_tile) {
+        const size_t oi = frame_first + (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
+        if (sh.rgb8) {
+            uint8_t* o3 = reinterpret_cast<uint8_t*>(out) + 3 * oi;
+            o3[0] = (uint8_t)rgba, o3[1] = (uint8_t)(rgba >> 8), o3[2] = (uint8_t)(rgba >> 16);
+        } else {
+            out[oi] = rgba;
+        }
+    }
     if (stats) flush_stats(stats, counts & 255u, (counts >> 8) & 255u, (counts >> 16) & 255u, counts >> 24, ctr);
 }
 

@@ -312,18 +312,18 @@ class TraceCore:
                                    _ptr(out)))
         return out
 
-    def render_frames(self, cams, width, height, shard=None, max_bounces=8, shadows=False, out=None):
-        """Up to 16 consecutive frames in one launch: (n_frames, n_pixels, 4) uint8. `cams`: sequence of
-        CameraUniform."""
+    def render_frames(self, cams, width, height, shard=None, max_bounces=8, shadows=False, out=None, rgb8=False):
+        """Up to 16 consecutive frames in one launch: (n_frames, n_pixels, 4) uint8, or (n_frames, n_pixels, 3)
+        with rgb8 (no alpha byte). `cams`: sequence of CameraUniform."""
         n = shard_pixels(width, height, shard)
         arr = (CameraUniform * len(cams))()
         for j, cam in enumerate(cams):
             C.memmove(C.byref(arr, j * C.sizeof(CameraUniform)), C.byref(cam), C.sizeof(CameraUniform))
         if out is None:
-            out = np.empty((len(cams), n, 4), np.uint8)
+            out = np.empty((len(cams), n, 3 if rgb8 else 4), np.uint8)
         o = RtRenderOpts()
         self._L.rt_default_render_opts(C.byref(o))
-        o.max_bounces, o.shadows = max_bounces, 1 if shadows else 0
+        o.max_bounces, o.shadows, o.pixel_format = max_bounces, 1 if shadows else 0, 1 if rgb8 else 0
         self._ck(self._L.rt_render_frames(self._h, arr, len(cams), width, height, _ref(shard, RtShard), C.byref(o), _ptr(out)))
         return out
 
@@ -331,6 +331,11 @@ class TraceCore:
                               images):
         self._ck(self._L.rt_assemble_frames_rgba8(self._h, _ptr(gathered), width, height, tile_w, tile_h, n_ranks, n_frames,
                                                   rank_stride, frame_stride, _ptr(images)))
+
+    def assemble_frames_rgb8(self, gathered, width, height, tile_w, tile_h, n_ranks, n_frames, rank_stride, frame_stride,
+                             images):
+        self._ck(self._L.rt_assemble_frames_rgb8(self._h, _ptr(gathered), width, height, tile_w, tile_h, n_ranks, n_frames,
+                                                 rank_stride, frame_stride, _ptr(images)))
 
     def debug_pixel(self, cam, width, height, px, py):
         info = RayDebugInfo()

@@ -94,10 +94,10 @@ class _GroupSlot:
     def __init__(self, sharder, device):
         s = sharder
         self.stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
-        self.local = torch.zeros((s.group, s.per_rank, 4), dtype=torch.uint8, device=device)
+        self.local = torch.zeros((s.group, s.per_rank, s.wire_bytes), dtype=torch.uint8, device=device)
         self.packed = self.images = None
         if s.rank == 0:
-            self.packed = torch.empty((s.world, s.group, s.per_rank, 4), dtype=torch.uint8, device=device)
+            self.packed = torch.empty((s.world, s.group, s.per_rank, s.wire_bytes), dtype=torch.uint8, device=device)
             self.images = torch.empty((s.group, s.height * s.width, 4), dtype=torch.uint8, device=device)
 
 
@@ -128,7 +128,7 @@ class FrameSharder:
         # only waits for work queued on torch's current stream, and makes that stream wait for its completion.
         self.slots = [_Slot(self, device) for _ in range(max(1, frames_in_flight))]
         self.frame = 0
-        self.group, self.gslots, self.group_no = 0, [], 0
+        self.group, self.gslots, self.group_no, self.wire_bytes = 0, [], 0, 4
         self.local, self.packed, self.image = self.slots[0].local, self.slots[0].packed, self.slots[0].image
 
     def _local(self, cam, slot):
@@ -161,13 +161,15 @@ class FrameSharder:
                 slot.stream.synchronize()
 
     # ---- groups of frames ("rgba" mode)
-    def enable_groups(self, group=8, groups_in_flight=2):
-        """Allocates buffers for `groups_in_flight` groups of up to `group` frames each."""
+    def enable_groups(self, group=8, groups_in_flight=2, rgb8=False):
+        """Allocates buffers for `groups_in_flight` groups of up to `group` frames each. rgb8: the pictures travel
+        without their constant alpha byte (3 bytes per pixel on the links instead of 4); rank 0 puts it back."""
         if self.mode != "rgba":
             raise ValueError("frame groups carry the shaded picture: mode must be 'rgba'")
         if not 1 <= group <= 16:
             raise ValueError("a group holds 1 to 16 frames (one rt_render_frames launch)")
         self.group = group
+        self.wire_bytes = 3 if rgb8 else 4
         self.gslots = [_GroupSlot(self, self.device) for _ in range(max(1, groups_in_flight))]
 
     def trace_group(self, cams):
@@ -187,15 +189,17 @@ class FrameSharder:
         return self._trace_group(cams, g, slot)
 
     def _trace_group(self, cams, g, slot):
+        rgb8 = self.wire_bytes == 3
         self.core.render_frames(cams, self.width, self.height, shard=self.shard, max_bounces=self.max_bounces,
-                                shadows=self.shadow, out=slot.local[:g])
+                                shadows=self.shadow, out=slot.local[:g], rgb8=rgb8)
         if self.world > 1:
             dist.gather(slot.local[:g], [slot.packed[r, :g] for r in range(self.world)] if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
         src = slot.packed if self.world > 1 else slot.local.unsqueeze(0)
-        self.core.assemble_frames_rgba8(src, self.width, self.height, self.tile_w, self.tile_h, self.world, g,
-                                        self.group * self.per_rank, self.per_rank, slot.images[:g])
+        assemble = self.core.assemble_frames_rgb8 if rgb8 else self.core.assemble_frames_rgba8
+        assemble(src, self.width, self.height, self.tile_w, self.tile_h, self.world, g, self.group * self.per_rank,
+                 self.per_rank, slot.images[:g])
         return slot.images[:g]
 
     def _trace(self, cam, slot):

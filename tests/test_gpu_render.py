@@ -219,14 +219,20 @@ def test_frame_groups_on_the_gpu_single_rank(core, ob, rt, car_xyz9):
     w, h = 300, 170
     cams = [rt.Camera((200.0 - 20 * j, 200.0, 300.0 - 10 * j), 3.35 + 0.02 * j, -0.28).to_uniform(0.0, float(h)) for j in range(7)]
     sh = sharding.FrameSharder(core, w, h, 64, 64, rank=0, world=1, device="cuda", shadow=True, mode="rgba", max_bounces=1)
-    sh.enable_groups(group=4, groups_in_flight=2)
-    a, b = sh.trace_group(cams[:4]), sh.trace_group(cams[4:])
-    sh.synchronize()
-    core.set_stream(None)
-    assert a.shape == (4, w * h, 4) and b.shape == (3, w * h, 4)
-    for j, pic in enumerate(list(a) + list(b)):
-        want, _ = ob.render(scene, ocam(ob, cams[j]), w, h, max_bounces=1, shadows=True)
-        assert np.array_equal(pic.cpu().numpy(), want), f"frame {j}"
+    wants = [ob.render(scene, ocam(ob, c), w, h, max_bounces=1, shadows=True)[0] for c in cams]
+    for rgb8 in (False, True):  # 4- and 3-byte pixels on the wire, the same pictures out
+        sh.enable_groups(group=4, groups_in_flight=2, rgb8=rgb8)
+        a, b = sh.trace_group(cams[:4]), sh.trace_group(cams[4:])
+        sh.synchronize()
+        core.set_stream(None)
+        assert a.shape == (4, w * h, 4) and b.shape == (3, w * h, 4)
+        for j, pic in enumerate(list(a) + list(b)):
+            assert np.array_equal(pic.cpu().numpy(), wants[j]), f"frame {j}, rgb8={rgb8}"
+    # the 3-byte picture itself: host output, one frame and several
+    got = core.render_frames(cams[:3], w, h, max_bounces=1, shadows=True, rgb8=True)
+    assert got.shape == (3, w * h, 3)
+    for j in range(3):
+        assert np.array_equal(got[j], wants[j][:, :3])
 
 
 def test_alpha_rules_hit_records_and_picture(core, ob, rt, car_xyz9):

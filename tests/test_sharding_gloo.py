@@ -35,9 +35,23 @@ class OracleCore:
                                 n_threads=2)
         out[:len(img)] = torch.from_numpy(img)
 
-    def render_frames(self, cams, width, height, shard=None, max_bounces=8, shadows=False, out=None):
+    def render_frames(self, cams, width, height, shard=None, max_bounces=8, shadows=False, out=None, rgb8=False):
         for j, cam in enumerate(cams):
-            self.render(cam, width, height, shard=shard, max_bounces=max_bounces, shadows=shadows, out=out[j])
+            if rgb8:
+                tmp = torch.zeros((out.shape[1], 4), dtype=torch.uint8)
+                self.render(cam, width, height, shard=shard, max_bounces=max_bounces, shadows=shadows, out=tmp)
+                out[j] = tmp[:, :3]
+            else:
+                self.render(cam, width, height, shard=shard, max_bounces=max_bounces, shadows=shadows, out=out[j])
+
+    def assemble_frames_rgb8(self, gathered, width, height, tile_w, tile_h, n_ranks, n_frames, rank_stride, frame_stride,
+                             images):
+        flat = gathered.reshape(-1, 3)
+        rgb = torch.empty((width * height, 3), dtype=torch.uint8)
+        for j in range(n_frames):
+            self._assemble(flat[j * frame_stride:], width, height, tile_w, tile_h, n_ranks, rgb, rank_stride, torch.uint8, 3)
+            images[j, :, :3] = rgb
+            images[j, :, 3] = 255
 
     def assemble_frames_rgba8(self, gathered, width, height, tile_w, tile_h, n_ranks, n_frames, rank_stride, frame_stride,
                               images):
@@ -109,7 +123,7 @@ def _worker(rank, world, port, tmp):
             open(os.path.join(tmp, "result_rgba"), "w").write(str(int(ok2)))
         # groups of frames: one launch, one gather, one assemble per group; a full group, then a partial one
         shg = sharding.FrameSharder(OracleCore(ob, scene), W, H, TW, TH, device="cpu", shadow=False, mode="rgba", max_bounces=1)
-        shg.enable_groups(group=3, groups_in_flight=2)
+        shg.enable_groups(group=3, groups_in_flight=2, rgb8=(world == 3))  # one world size per wire format
         cams = [cam, cam2, ob.camera_to_uniform((150, 120, 250), 3.4, -0.3, 0.0, float(H)), cam2, cam]
         first, second = shg.trace_group(cams[:3]), shg.trace_group(cams[3:])
         if rank == 0:

@@ -33,14 +33,14 @@ def main():
                 sh = sharding.FrameSharder(core, W, H, TILE, TILE, rank=rank, world=1, device=dev, shadow=True, mode="rgba", max_bounces=1)
                 sh.shard = rt.RtShard(TILE, TILE, rank, world)  # this rank's tiles of a `world`-GPU run, no gather
                 sh.per_rank = sharding.per_rank_pixels(W, H, TILE, TILE, world)
-                sh.enable_groups(group, in_flight)
+                sh.enable_groups(group, in_flight, rgb8=True)
                 cams = [cam] * group
                 slots = sh.gslots
                 def run(n):
                     for k in range(n):
                         slot = slots[k % len(slots)]
                         core.set_stream(slot.stream.cuda_stream)
-                        core.render_frames(cams, W, H, shard=sh.shard, max_bounces=1, shadows=True, out=slot.local)
+                        core.render_frames(cams, W, H, shard=sh.shard, max_bounces=1, shadows=True, out=slot.local, rgb8=True)
                     core.sync()
                 run(10)
                 n = max(10, 400 // group)

@@ -16,6 +16,7 @@ from ray_tracer_amd import sharding  # noqa: E402
 
 W, H = 1920, 1080
 TILE = int(os.environ.get("RT_TILE", "32"))
+TILE_H = int(os.environ.get("RT_TILE_H", str(TILE)))
 
 
 def main():
@@ -27,12 +28,12 @@ def main():
     cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
     out = []
     for world in [int(x) for x in os.environ.get('RT_WORLDS', '1,2,4,8').split(',')]:
-        for group, in_flight in ((1, 4), (4, 3), (8, 3), (16, 2)) if 'RT_QUICK' not in os.environ else ((8, 3), (16, 2)):
+        for group, in_flight in ((1, 4), (4, 3), (8, 3), (16, 2)) if 'RT_QUICK' not in os.environ else (((8, 2),) if os.environ['RT_QUICK'] == '2' else ((8, 3), (16, 2))):
             per_rank = []
-            for rank in range(world):
-                sh = sharding.FrameSharder(core, W, H, TILE, TILE, rank=rank, world=1, device=dev, shadow=True, mode="rgba", max_bounces=1)
-                sh.shard = rt.RtShard(TILE, TILE, rank, world)  # this rank's tiles of a `world`-GPU run, no gather
-                sh.per_rank = sharding.per_rank_pixels(W, H, TILE, TILE, world)
+            for rank in (range(world - 1, -1, -1) if os.environ.get('RT_REVERSE') else range(world)):
+                sh = sharding.FrameSharder(core, W, H, TILE, TILE_H, rank=rank, world=1, device=dev, shadow=True, mode="rgba", max_bounces=1)
+                sh.shard = rt.RtShard(TILE, TILE_H, rank, world)  # this rank's tiles of a `world`-GPU run, no gather
+                sh.per_rank = sharding.per_rank_pixels(W, H, TILE, TILE_H, world)
                 sh.enable_groups(group, in_flight, rgb8=True)
                 cams = [cam] * group
                 slots = sh.gslots
@@ -43,7 +44,7 @@ def main():
                         core.render_frames(cams, W, H, shard=sh.shard, max_bounces=1, shadows=True, out=slot.local, rgb8=True)
                     core.sync()
                 run(10)
-                n = max(10, 400 // group)
+                n = max(10, int(os.environ.get('RT_FRAMES', '400')) // group)
                 t0 = time.perf_counter()
                 run(n)
                 per_rank.append((time.perf_counter() - t0) / (n * group) * 1e6)

@@ -41,9 +41,10 @@ TILE = 32
 FRAMES_IN_FLIGHT = 2
 # At N > 1 a rank owns 1/N of the tiles but its slowest pixel block still is a ~100 us dependent chain, and every
 # frame also spends time on the links: more frames have to be in flight to keep the GPUs busy.
-# frames per launch / gather / assemble at N > 1 (8 and 16 measure alike on the GPU side; gloo, used to rehearse this
-# path on one GPU, stalls on the 64 MB tensors that 16 frames make at N = 2)
-GROUP = int(os.environ.get("RT_BENCH_GROUP", "8"))
+# Frames per gather / assemble at N > 1 (rendered 16 to a launch). At N = 8 a rank's share of a frame is ~10 us of GPU
+# time, so a group must hold enough frames for one collective's host cost (a few hundred us through Python) to hide
+# behind its rendering.
+GROUP = int(os.environ.get("RT_BENCH_GROUP", "32"))
 GROUPS_IN_FLIGHT = int(os.environ.get("RT_BENCH_GROUPS_IN_FLIGHT", "2"))
 
 
@@ -266,7 +267,7 @@ def main():
                        "primary_hits": stats["primary_hits"], "grid": list(meta.fine_dims), "cell_size": 16.0,
                        "cells": n_cells, "cell_refs": n_refs,
                        "frames_in_flight": FRAMES_IN_FLIGHT if world == 1 else GROUP * GROUPS_IN_FLIGHT,
-                       "frames_per_launch_and_gather": 1 if world == 1 else GROUP,
+                       "frames_per_gather": 1 if world == 1 else GROUP, "frames_per_launch": 1 if world == 1 else min(GROUP, 16),
                        "output": "rt_hit records, 16 B per pixel, resident in HBM" if world == 1 else
                                  "shaded RGBA8 picture (ambient + diffuse with the shadow-ray term) assembled on rank 0; 3 B per pixel on the links (alpha is constant)",
                        "parallelism": "single GPU" if world == 1 else f"{TILE}x{TILE} tiles round-robin over {world} GPUs, RCCL gather to rank 0"},

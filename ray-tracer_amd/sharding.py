@@ -19,7 +19,7 @@ frame shards without any data-path exchange until the end:
 No step synchronises the host. Frames can be kept in flight (separate streams and buffers per frame), which
 overlaps a frame's gather, and the long tail of its trace kernel, with the next frame's tracing.
 For throughput (a camera path rendered ahead of display) frames travel in GROUPS: `trace_group` renders this rank's
-tiles of up to 16 consecutive frames in one launch (rt_render_frames), gathers them in one collective and assembles
+tiles of up to 64 consecutive frames in one to four launches (rt_render_frames), gathers them in one collective and assembles
 them in one launch, so launch, collective and host costs are paid once per group instead of once per frame, and
 the expensive pixel blocks of one frame overlap the other frames of the group. Groups are kept in flight like
 frames.
@@ -96,6 +96,7 @@ class _GroupSlot:
         self.stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
         self.local = torch.zeros((s.group, s.per_rank, s.wire_bytes), dtype=torch.uint8, device=device)
         self.packed = self.images = None
+        self.views = {}
         if s.rank == 0:
             self.packed = torch.empty((s.world, s.group, s.per_rank, s.wire_bytes), dtype=torch.uint8, device=device)
             self.images = torch.empty((s.group, s.height * s.width, 4), dtype=torch.uint8, device=device)
@@ -166,8 +167,8 @@ class FrameSharder:
         without their constant alpha byte (3 bytes per pixel on the links instead of 4); rank 0 puts it back."""
         if self.mode != "rgba":
             raise ValueError("frame groups carry the shaded picture: mode must be 'rgba'")
-        if not 1 <= group <= 16:
-            raise ValueError("a group holds 1 to 16 frames (one rt_render_frames launch)")
+        if not 1 <= group <= 64:
+            raise ValueError("a group holds 1 to 64 frames (up to four rt_render_frames launches of 16)")
         self.group = group
         self.wire_bytes = 3 if rgb8 else 4
         self.gslots = [_GroupSlot(self, self.device) for _ in range(max(1, groups_in_flight))]
@@ -190,10 +191,14 @@ class FrameSharder:
 
     def _trace_group(self, cams, g, slot):
         rgb8 = self.wire_bytes == 3
-        self.core.render_frames(cams, self.width, self.height, shard=self.shard, max_bounces=self.max_bounces,
-                                shadows=self.shadow, out=slot.local[:g], rgb8=rgb8)
+        for j in range(0, g, 16):  # one launch renders up to 16 frames
+            self.core.render_frames(cams[j:j + 16], self.width, self.height, shard=self.shard, max_bounces=self.max_bounces,
+                                    shadows=self.shadow, out=slot.local[j:min(g, j + 16)], rgb8=rgb8)
         if self.world > 1:
-            dist.gather(slot.local[:g], [slot.packed[r, :g] for r in range(self.world)] if self.rank == 0 else None, dst=0)
+            if g not in slot.views:  # tensor views are not free to make: once per group length
+                slot.views[g] = (slot.local[:g], [slot.packed[r, :g] for r in range(self.world)] if self.rank == 0 else None)
+            mine, parts = slot.views[g]
+            dist.gather(mine, parts, dst=0)
         if self.rank != 0:
             return None
         src = slot.packed if self.world > 1 else slot.local.unsqueeze(0)

@@ -228,6 +228,13 @@ def test_frame_groups_on_the_gpu_single_rank(core, ob, rt, car_xyz9):
         assert a.shape == (4, w * h, 4) and b.shape == (3, w * h, 4)
         for j, pic in enumerate(list(a) + list(b)):
             assert np.array_equal(pic.cpu().numpy(), wants[j]), f"frame {j}, rgb8={rgb8}"
+    # a group longer than one launch holds (16 frames): 20 frames, two launches, one assemble
+    sh.enable_groups(group=20, groups_in_flight=1, rgb8=True)
+    many = sh.trace_group([cams[j % 7] for j in range(20)])
+    sh.synchronize()
+    core.set_stream(None)
+    for j in (0, 15, 16, 19):
+        assert np.array_equal(many[j].cpu().numpy(), wants[j % 7]), f"frame {j} of 20"
     # the 3-byte picture itself: host output, one frame and several
     got = core.render_frames(cams[:3], w, h, max_bounces=1, shadows=True, rgb8=True)
     assert got.shape == (3, w * h, 3)

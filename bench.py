@@ -9,7 +9,7 @@ hit, all inside one kernel launch, with scene, grid and output buffers resident 
 with a two-image swap chain, consecutive frames go to two streams with their own output buffers (two frames in
 flight): a frame's last waves - a few pixel blocks over the model's densest cells, one long dependent chain
 each - then overlap the next frame's bulk instead of leaving the GPU idle. At N > 1
-the SAME frame is cut into 64x64 tiles dealt round-robin to the ranks, each rank shades its tiles (same
+the SAME frame is cut into 32x32 tiles dealt round-robin to the ranks, each rank shades its tiles (same
 primary + shadow rays) and the RGBA8 framebuffer is gathered on rank 0 by RCCL (total work fixed: strong
 scaling; 3 bytes per pixel cross the links - the picture without its constant alpha byte - instead of 16 for hit
 records). A rank's share of one 1080p frame is
@@ -134,11 +134,18 @@ def main():
     # Rehearsal on a one-GPU box: RT_BENCH_ONE_GPU=1 puts every rank on GPU 0 and uses gloo (RCCL refuses two
     # ranks on one device). Never set by the driver.
     rehearsal = os.environ.get("RT_BENCH_ONE_GPU") == "1"
+    # Development: RT_BENCH_RCCL_WORLD1=1 takes the N > 1 route (RCCL communicator, broadcast, gather, assemble) with
+    # a single rank, which is all of that route a one-GPU box can run on the real backend. Never set by the driver.
+    multi = world > 1 or os.environ.get("RT_BENCH_RCCL_WORLD1") == "1"
+    if multi and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -147,7 +154,7 @@ def main():
 
     xyz9 = np.load(os.path.join(ROOT, "tests", "golden", "car_tris.npy"))
     tris = rt.triangles_from_xyz9(xyz9) if rank == 0 else None
-    if world > 1:  # scene replicated by one RCCL broadcast, grid binned locally on every GPU
+    if multi:  # scene replicated by one RCCL broadcast, grid binned locally on every GPU
         _, tris = sharding.broadcast_scene(np.zeros(0, rt.BOX_DTYPE) if rank == 0 else None, tris, dev)
     core = rt.TraceCore(local_rank)
     core.set_scene(None, tris)
@@ -161,7 +168,7 @@ def main():
     core.set_collect_stats(False)
     rays_per_frame = stats["rays"]
 
-    if world == 1:
+    if not multi:
         streams = [torch.cuda.Stream(device=dev) for _ in range(FRAMES_IN_FLIGHT)]
         bufs = [(torch.empty((WIDTH * HEIGHT, 2), dtype=torch.int32, device=dev),
                  torch.empty((WIDTH * HEIGHT, 2), dtype=torch.int32, device=dev)) for _ in range(FRAMES_IN_FLIGHT)]
@@ -211,32 +218,32 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     kernel_ms = None
-    if world == 1:  # HIP events on the streams the kernels are launched on
+    if not multi:  # HIP events on the streams the kernels are launched on
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
         for (e0, _), st in zip(ev, streams):
             e0.record(st)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world == 1:
+    if not multi:
         for (_, e1), st in zip(ev, streams):
             e1.record(st)
     sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world == 1:
+    if not multi:
         # average time one launch occupies its stream; with two frames in flight two launches overlap, so this
         # is about twice the time per frame
         per_stream = [(args.steps + FRAMES_IN_FLIGHT - 1 - k) // FRAMES_IN_FLIGHT for k in range(FRAMES_IN_FLIGHT)]
         kernel_ms = float(np.mean([e0.elapsed_time(e1) / n for (e0, e1), n in zip(ev, per_stream) if n]))
     hbm_copy = None
-    if world == 1:  # what this GPU's HBM delivers on a plain copy (2 GiB read + 2 GiB written), beside the 8 TB/s spec
+    if not multi:  # what this GPU's HBM delivers on a plain copy (2 GiB read + 2 GiB written), beside the 8 TB/s spec
         a = torch.empty(1 << 29, dtype=torch.float32, device=dev)
         b = torch.empty_like(a)
         b.copy_(a)
@@ -248,7 +255,7 @@ def main():
         torch.cuda.synchronize()
         hbm_copy = 2 * a.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -266,13 +273,13 @@ def main():
                        "width": WIDTH, "height": HEIGHT, "rays_per_frame": rays_per_frame,
                        "primary_hits": stats["primary_hits"], "grid": list(meta.fine_dims), "cell_size": 16.0,
                        "cells": n_cells, "cell_refs": n_refs,
-                       "frames_in_flight": FRAMES_IN_FLIGHT if world == 1 else GROUP * GROUPS_IN_FLIGHT,
-                       "frames_per_gather": 1 if world == 1 else GROUP, "frames_per_launch": 1 if world == 1 else min(GROUP, 16),
-                       "output": "rt_hit records, 16 B per pixel, resident in HBM" if world == 1 else
+                       "frames_in_flight": FRAMES_IN_FLIGHT if not multi else GROUP * GROUPS_IN_FLIGHT,
+                       "frames_per_gather": 1 if not multi else GROUP, "frames_per_launch": 1 if not multi else min(GROUP, 16),
+                       "output": "rt_hit records, 16 B per pixel, resident in HBM" if not multi else
                                  "shaded RGBA8 picture (ambient + diffuse with the shadow-ray term) assembled on rank 0; 3 B per pixel on the links (alpha is constant)",
-                       "parallelism": "single GPU" if world == 1 else f"{TILE}x{TILE} tiles round-robin over {world} GPUs, RCCL gather to rank 0"},
+                       "parallelism": "single GPU" if not multi else f"{TILE}x{TILE} tiles round-robin over {world} GPUs, RCCL gather to rank 0"},
         }
-        if world == 1:
+        if not multi:
             abytes = algorithmic_bytes(stats)
             achieved = abytes / (kernel_ms * 1e-3) / 1e9
             traffic = None
@@ -290,7 +297,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(xyz9, WIDTH, HEIGHT)
         print(json.dumps(out), flush=True)
     core.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

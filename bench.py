@@ -185,7 +185,7 @@ def main():
     else:
         # the framebuffer that travels is the shaded RGBA8 picture; one bounce = the same primary + shadow rays
         sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
-                                   frames_in_flight=1, max_bounces=1)
+                                   frames_in_flight=1, max_bounces=1, collective=True)
         sh.enable_groups(GROUP, GROUPS_IN_FLIGHT, rgb8=os.environ.get("RT_BENCH_WIRE", "rgb") == "rgb")  # the constant alpha byte stays at home
         if os.environ.get("RT_BENCH_TRACE"):  # development: where every rank is, every few seconds
             import threading

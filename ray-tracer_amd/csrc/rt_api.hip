@@ -166,6 +166,26 @@ __global__ void k_assemble(const PIXEL* __restrict__ gathered, uint32_t width, u
     image[(size_t)y * width + x] = gathered[src];
 }
 
+// The same for layouts where 16 bytes of a row (PER pixels) never straddle a tile or the image edge: one workgroup per
+// tile, 16-byte loads and stores, the tile -> (rank, block) arithmetic once per workgroup.
+template <uint32_t PER>
+__global__ __launch_bounds__(256) void k_assemble_x16(const uint4* __restrict__ gathered, uint32_t width, uint32_t height,
+                                                      uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks,
+                                                      size_t per_rank, size_t frame_stride, uint4* __restrict__ image) {
+    const uint32_t tile = blockIdx.y * tiles_x + blockIdx.x;
+    const uint32_t rank = tile % n_ranks, lt = tile / n_ranks;
+    const uint32_t x0 = blockIdx.x * tile_w, y0 = blockIdx.y * tile_h;
+    const uint32_t vec_x = tile_w / PER;
+    const uint32_t cols = min(vec_x, (width - x0) / PER), rows = min(tile_h, height - y0);
+    const uint4* src = gathered + ((size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h) / PER;
+    uint4* dst = image + ((size_t)blockIdx.z * width * height + (size_t)y0 * width + x0) / PER;
+    const uint32_t n = vec_x * rows;
+    for (uint32_t q = threadIdx.x; q < n; q += blockDim.x) {
+        const uint32_t ly = q / vec_x, lq = q - ly * vec_x;
+        if (lq < cols) dst[(size_t)ly * (width / PER) + lq] = src[q];
+    }
+}
+
 // ---------------------------------------------------------------- host helpers
 
 int use(rt_ctx* c) {
@@ -864,9 +884,19 @@ static int assemble_tiles(rt_ctx* c, const void* gathered, uint32_t width, uint3
     if (n_frames > 65535u) return fail(c, RT_ERR_LIMIT, "%s: more than 65535 frames", who);
     if (n_frames > 1 && (frame_stride < min_stride || per_rank < (size_t)n_frames * min_stride))
         return fail(c, RT_ERR_INVALID, "%s: frame_stride / rank_stride smaller than the frames they hold", who);
-    hipLaunchKernelGGL(k_assemble<PIXEL>, dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream,
-                       reinterpret_cast<const PIXEL*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks, per_rank,
-                       frame_stride, reinterpret_cast<PIXEL*>(image));
+    constexpr uint32_t PER = 16 / sizeof(PIXEL);
+    const bool by_vectors = tile_w % PER == 0 && width % PER == 0 && per_rank % PER == 0 &&
+                            (n_frames == 1 || frame_stride % PER == 0) && reinterpret_cast<uintptr_t>(gathered) % 16 == 0 &&
+                            reinterpret_cast<uintptr_t>(image) % 16 == 0 && tiles_y <= 65535u &&
+                            (uint64_t)tile_w * tile_h / PER <= 0xFFFFFFFFull;
+    if (by_vectors)
+        hipLaunchKernelGGL(k_assemble_x16<PER>, dim3(tiles_x, tiles_y, n_frames), dim3(256), 0, c->stream,
+                           reinterpret_cast<const uint4*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks, per_rank,
+                           frame_stride, reinterpret_cast<uint4*>(image));
+    else
+        hipLaunchKernelGGL(k_assemble<PIXEL>, dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream,
+                           reinterpret_cast<const PIXEL*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks, per_rank,
+                           frame_stride, reinterpret_cast<PIXEL*>(image));
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -905,6 +935,36 @@ __global__ void k_assemble_rgb8(const uint8_t* __restrict__ gathered, uint32_t w
         (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
 }
 
+// The same for layouts where four pixels of a row never straddle a tile or the image edge (tile_w and width multiples of
+// 4, strides multiples of 4 pixels, buffers 16-byte aligned): one workgroup per tile, a thread moves four pixels at a
+// time - three dwords in, one 16-byte store out - and the tile -> (rank, block) arithmetic is done once per workgroup.
+__global__ __launch_bounds__(256) void k_assemble_rgb8_x4(const uint32_t* __restrict__ gathered, uint32_t width, uint32_t height,
+                                                          uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks,
+                                                          size_t per_rank, size_t frame_stride, uint4* __restrict__ image) {
+    const uint32_t tile = blockIdx.y * tiles_x + blockIdx.x;
+    const uint32_t rank = tile % n_ranks, lt = tile / n_ranks;
+    const uint32_t x0 = blockIdx.x * tile_w, y0 = blockIdx.y * tile_h;
+    const uint32_t quads_x = tile_w / 4;
+    const uint32_t cols = min(quads_x, (width - x0) / 4), rows = min(tile_h, height - y0);
+    // pixel index of the tile's first record; a multiple of 4, so 3 bytes * index is a whole number of dwords
+    const size_t first = (size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h;
+    const uint32_t* src = gathered + first / 4 * 3;
+    uint4* dst = image + ((size_t)blockIdx.z * width * height + (size_t)y0 * width + x0) / 4;
+    const uint32_t n = quads_x * rows;
+    for (uint32_t q = threadIdx.x; q < n; q += blockDim.x) {
+        const uint32_t ly = q / quads_x, lq = q - ly * quads_x;
+        if (lq >= cols) continue;
+        const uint32_t* p = src + 3 * (size_t)q;
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        uint4 o;
+        o.x = (d0 & 0x00FFFFFFu) | 0xFF000000u;
+        o.y = (d0 >> 24) | ((d1 & 0x0000FFFFu) << 8) | 0xFF000000u;
+        o.z = (d1 >> 16) | ((d2 & 0x000000FFu) << 16) | 0xFF000000u;
+        o.w = (d2 >> 8) | 0xFF000000u;
+        dst[(size_t)ly * (width / 4) + lq] = o;
+    }
+}
+
 extern "C" int rt_assemble_frames_rgb8(rt_ctx* c, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
                                        uint32_t tile_h, uint32_t n_ranks, uint32_t n_frames, size_t rank_stride,
                                        size_t frame_stride, uint8_t* images) {
@@ -921,8 +981,16 @@ extern "C" int rt_assemble_frames_rgb8(rt_ctx* c, const uint8_t* gathered, uint3
     if (n_frames > 65535u) return fail(c, RT_ERR_LIMIT, "%s: more than 65535 frames", who);
     if (per_rank < min_stride || (n_frames > 1 && (frame_stride < min_stride || per_rank < (size_t)n_frames * min_stride)))
         return fail(c, RT_ERR_INVALID, "%s: frame_stride / rank_stride smaller than the frames they hold", who);
-    hipLaunchKernelGGL(k_assemble_rgb8, dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream, gathered, width,
-                       height, tile_w, tile_h, tiles_x, n_ranks, per_rank, frame_stride, reinterpret_cast<uint32_t*>(images));
+    const bool by_fours = tile_w % 4 == 0 && width % 4 == 0 && per_rank % 4 == 0 && (n_frames == 1 || frame_stride % 4 == 0) &&
+                          reinterpret_cast<uintptr_t>(gathered) % 16 == 0 && reinterpret_cast<uintptr_t>(images) % 16 == 0 &&
+                          tiles_y <= 65535u && (uint64_t)tile_w * tile_h / 4 <= 0xFFFFFFFFull;
+    if (by_fours)
+        hipLaunchKernelGGL(k_assemble_rgb8_x4, dim3(tiles_x, tiles_y, n_frames), dim3(256), 0, c->stream,
+                           reinterpret_cast<const uint32_t*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks, per_rank,
+                           frame_stride, reinterpret_cast<uint4*>(images));
+    else
+        hipLaunchKernelGGL(k_assemble_rgb8, dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream, gathered, width,
+                           height, tile_w, tile_h, tiles_x, n_ranks, per_rank, frame_stride, reinterpret_cast<uint32_t*>(images));
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

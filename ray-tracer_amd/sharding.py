@@ -114,13 +114,15 @@ class FrameSharder:
                  valid until that many further frames have been started."""
 
     def __init__(self, core, width, height, tile_w=64, tile_h=64, rank=None, world=None, device="cuda", shadow=True,
-                 mode="hits", frames_in_flight=1, max_bounces=8):
+                 mode="hits", frames_in_flight=1, max_bounces=8, collective=None):
         if mode not in ("hits", "rgba"):
             raise ValueError("mode must be 'hits' or 'rgba'")
         self.core, self.width, self.height, self.tile_w, self.tile_h = core, width, height, tile_w, tile_h
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
         self.shadow, self.mode, self.max_bounces = shadow, mode, max_bounces
+        # the gather is skipped for a lone rank unless asked for (a one-rank process group exercises the backend)
+        self.collective = self.world > 1 if collective is None else bool(collective)
         self.device = device
         self.shard = RtShard(tile_w, tile_h, self.rank, self.world)
         self.per_rank = per_rank_pixels(width, height, tile_w, tile_h, self.world)
@@ -194,14 +196,14 @@ class FrameSharder:
         for j in range(0, g, 16):  # one launch renders up to 16 frames
             self.core.render_frames(cams[j:j + 16], self.width, self.height, shard=self.shard, max_bounces=self.max_bounces,
                                     shadows=self.shadow, out=slot.local[j:min(g, j + 16)], rgb8=rgb8)
-        if self.world > 1:
+        if self.collective:
             if g not in slot.views:  # tensor views are not free to make: once per group length
                 slot.views[g] = (slot.local[:g], [slot.packed[r, :g] for r in range(self.world)] if self.rank == 0 else None)
             mine, parts = slot.views[g]
             dist.gather(mine, parts, dst=0)
         if self.rank != 0:
             return None
-        src = slot.packed if self.world > 1 else slot.local.unsqueeze(0)
+        src = slot.packed if self.collective else slot.local.unsqueeze(0)
         assemble = self.core.assemble_frames_rgb8 if rgb8 else self.core.assemble_frames_rgba8
         assemble(src, self.width, self.height, self.tile_w, self.tile_h, self.world, g, self.group * self.per_rank,
                  self.per_rank, slot.images[:g])
@@ -209,11 +211,11 @@ class FrameSharder:
 
     def _trace(self, cam, slot):
         self._local(cam, slot)
-        if self.world > 1:
+        if self.collective:
             dist.gather(slot.local, slot.gathered, dst=0)
         if self.rank != 0:
             return None
-        src = slot.packed if self.world > 1 else slot.local.unsqueeze(0)
+        src = slot.packed if self.collective else slot.local.unsqueeze(0)
         if self.mode == "rgba":
             self.core.assemble_tiles_rgba8(src[0], self.width, self.height, self.tile_w, self.tile_h, self.world,
                                            slot.image, rank_stride=self.per_rank)

@@ -284,3 +284,63 @@ def test_alpha_rules_hit_records_and_picture(core, ob, rt, car_xyz9):
     assert core.stats() == st
     core.set_collect_stats(False)
     core.set_materials(None)
+
+
+def _scatter(packed, w, h, tw, th, world, n_frames, alpha):
+    """numpy restatement of the assemble kernels: packed is [rank][frame][record][bytes]."""
+    tx, ty = -(-w // tw), -(-h // th)
+    per = packed.shape[-1]
+    out = np.zeros((n_frames, h, w, per if alpha is None else 4), packed.dtype)
+    if alpha is not None:
+        out[..., 3] = alpha
+    for tile in range(tx * ty):
+        r, lt = tile % world, tile // world
+        x0, y0 = (tile % tx) * tw, (tile // tx) * th
+        hh, ww = min(th, h - y0), min(tw, w - x0)
+        blk = packed[r, :, lt * tw * th:(lt + 1) * tw * th].reshape(n_frames, th, tw, per)
+        out[:, y0:y0 + hh, x0:x0 + ww, :per] = blk[:, :hh, :ww]
+    return out.reshape(n_frames, h * w, -1)
+
+
+@pytest.mark.parametrize("w,h,tw,th,world", [
+    (1920, 1080, 32, 32, 8),   # what the benchmark uses: vector kernels, bottom tiles cut by the image
+    (200, 120, 64, 16, 3),     # right and bottom tiles cut
+    (202, 61, 20, 7, 2),       # width not a multiple of 4: the pixel-at-a-time kernels
+    (120, 50, 6, 5, 5),        # tile width not a multiple of 4
+    (64, 64, 64, 64, 1),
+])
+def test_assemble_kernels_equal_a_numpy_scatter(core, rt, w, h, tw, th, world):
+    """The gathering rank's kernels move bytes and nothing else: every layout - 16-byte vector path or one pixel per
+    thread - must equal a plain scatter of the same blocks (hit records, RGBA8 and RGB8 pictures, several frames)."""
+    import torch
+    from ray_tracer_amd import sharding
+    rng = np.random.default_rng(w * 31 + tw)
+    per_rank = sharding.per_rank_pixels(w, h, tw, th, world)
+    n_frames = 3
+    for per, dtype in ((3, np.uint8), (4, np.uint8)):
+        packed = rng.integers(0, 256, (world, n_frames, per_rank, per)).astype(dtype)
+        if per == 4:
+            packed[..., 3] = 255
+        dev = torch.from_numpy(packed).cuda()
+        images = torch.zeros((n_frames, h * w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        fn = core.assemble_frames_rgb8 if per == 3 else core.assemble_frames_rgba8
+        fn(dev, w, h, tw, th, world, n_frames, n_frames * per_rank, per_rank, images)
+        core.sync()
+        want = _scatter(packed, w, h, tw, th, world, n_frames, 255)
+        assert np.array_equal(images.cpu().numpy(), want), f"{per}-byte pictures, {w}x{h} tiles {tw}x{th} over {world}"
+    # hit records (8 bytes), one frame, and the one-frame RGBA8 entry point
+    hits = rng.integers(-2**31, 2**31 - 1, (world, 1, per_rank, 2)).astype(np.int32)
+    dev = torch.from_numpy(hits).cuda()
+    image = torch.zeros((h * w, 2), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    core.assemble_tiles(dev, w, h, tw, th, world, image, rank_stride=per_rank)
+    core.sync()
+    assert np.array_equal(image.cpu().numpy(), _scatter(hits, w, h, tw, th, world, 1, None)[0])
+    pic = rng.integers(0, 256, (world, 1, per_rank, 4)).astype(np.uint8)
+    dev = torch.from_numpy(pic).cuda()
+    image = torch.zeros((h * w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    core.assemble_tiles_rgba8(dev, w, h, tw, th, world, image, rank_stride=per_rank)
+    core.sync()
+    assert np.array_equal(image.cpu().numpy(), _scatter(pic, w, h, tw, th, world, 1, None)[0])

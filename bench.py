@@ -184,8 +184,12 @@ def main():
             core.sync()
     else:
         # the framebuffer that travels is the shaded RGBA8 picture; one bounce = the same primary + shadow rays
+        # rank 0 also receives and assembles every frame, so it renders a smaller share: 5 tiles of every 61 at
+        # N = 8 where the others render 8 (RT_BENCH_WEIGHTS=equal, or a comma-separated list, for experiments)
+        wenv = os.environ.get("RT_BENCH_WEIGHTS", "")
+        weights = None if wenv == "equal" else [int(k) for k in wenv.split(",")] if wenv else sharding.gatherer_weights(world)
         sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
-                                   frames_in_flight=1, max_bounces=1, collective=True)
+                                   frames_in_flight=1, max_bounces=1, collective=True, weights=weights)
         sh.enable_groups(GROUP, GROUPS_IN_FLIGHT, rgb8=os.environ.get("RT_BENCH_WIRE", "rgb") == "rgb")  # the constant alpha byte stays at home
         if os.environ.get("RT_BENCH_TRACE"):  # development: where every rank is, every few seconds
             import threading
@@ -277,7 +281,8 @@ def main():
                        "frames_per_gather": 1 if not multi else GROUP, "frames_per_launch": 1 if not multi else min(GROUP, 16),
                        "output": "rt_hit records, 16 B per pixel, resident in HBM" if not multi else
                                  "shaded RGBA8 picture (ambient + diffuse with the shadow-ray term) assembled on rank 0; 3 B per pixel on the links (alpha is constant)",
-                       "parallelism": "single GPU" if not multi else f"{TILE}x{TILE} tiles round-robin over {world} GPUs, RCCL gather to rank 0"},
+                       "parallelism": "single GPU" if not multi else f"{TILE}x{TILE} tiles dealt over {world} GPUs, "
+                                      f"{sh.weights or [1] * world} of every {sum(sh.weights or [1] * world)} (the gathering rank renders less), RCCL gather to rank 0"},
         }
         if not multi:
             abytes = algorithmic_bytes(stats)

@@ -18,7 +18,7 @@ pub struct RtParams {
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
-pub struct RtShard { pub tile_w: u32, pub tile_h: u32, pub first: u32, pub stride: u32 }
+pub struct RtShard { pub tile_w: u32, pub tile_h: u32, pub first: u32, pub stride: u32, pub owner: *const u32 }
 
 #[repr(C)]
 pub struct RtCtx { _private: [u8; 0] }
@@ -47,6 +47,9 @@ extern "C" {
                             shard: *const c_void, opts: *const c_void, out_rgba8: *mut u8) -> c_int;
     pub fn rt_assemble_frames_rgb8(ctx: *mut RtCtx, gathered: *const u8, width: u32, height: u32, tile_w: u32, tile_h: u32,
                                    n_ranks: u32, n_frames: u32, rank_stride: usize, frame_stride: usize, images: *mut u8) -> c_int;
+    pub fn rt_assemble_frames(ctx: *mut RtCtx, gathered: *const u8, pixel_format: u32, width: u32, height: u32, tile_w: u32,
+                              tile_h: u32, n_ranks: u32, owner: *const u32, round: u32, n_frames: u32, rank_stride: usize,
+                              frame_stride: usize, images: *mut u8) -> c_int;
     pub fn rt_assemble_frames_rgba8(ctx: *mut RtCtx, gathered: *const u8, width: u32, height: u32, tile_w: u32, tile_h: u32,
                                     n_ranks: u32, n_frames: u32, rank_stride: usize, frame_stride: usize, images: *mut u8) -> c_int;
     pub fn rt_set_skin(ctx: *mut RtCtx, positions: *const f32, joints: *const u16, weights: *const f32, n_vertices: u32,
@@ -65,7 +68,7 @@ extern "C" {
 /// `rt_render_opts` of include/rt_mi355.h.
 #[repr(C)]
 #[derive(Copy, Clone, Default)]
-pub struct RtRenderOpts { pub max_bounces: u32, pub shadows: u32, pub debug_enabled: u32, pub debug_pixel: [u32; 2], pub pixel_format: u32, pub _pad: [u32; 2] }
+pub struct RtRenderOpts { pub max_bounces: u32, pub shadows: u32, pub debug_enabled: u32, pub debug_pixel: [u32; 2], pub pixel_format: u32, pub frame_stride: u32, pub _pad: u32 }
 
 /// Owns one context. `Send` but not `Sync`: the C side is not re-entrant (one in-order stream).
 pub struct TraceCore { ctx: *mut RtCtx }

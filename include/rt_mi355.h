@@ -80,14 +80,21 @@ typedef struct rt_params {
 } rt_params;
 
 /* Which pixels of a W x H frame one call traces. The frame is cut into
- * tile_w x tile_h tiles numbered row-major; the call traces tiles first,
- * first+stride, first+2*stride, ... and packs them in that order: local tile j
- * occupies out[j*tile_w*tile_h ...] in tile-local row-major order (pixels of an
- * edge tile that fall outside the frame are written as misses). A NULL shard means
- * the whole frame, row-major. */
+ * tile_w x tile_h tiles numbered row-major, and the tiles into rounds of `stride`
+ * consecutive tiles. With owner == NULL the call traces tile `first` of every round
+ * (tiles first, first+stride, first+2*stride, ...). With an owner table - `stride`
+ * entries of host memory, owner[o] = the rank that traces tile o of every round - it
+ * traces the tiles whose owner is `first`, so ranks can own unequal shares of the
+ * frame, spread over it as finely as the table says: a rank that also gathers and
+ * assembles can be given less to trace (rt_assemble_frames takes the same table).
+ * Either way the tiles are packed in increasing tile order: local tile j occupies
+ * out[j*tile_w*tile_h ...] in tile-local row-major order (pixels of an edge tile that
+ * fall outside the frame are written as misses). A NULL shard means the whole frame,
+ * row-major. Tables of up to 4096 entries. */
 typedef struct rt_shard {
     uint32_t tile_w, tile_h;
     uint32_t first, stride;
+    const uint32_t* owner;
 } rt_shard;
 
 /* Work counters of the most recent stats-enabled trace call. */
@@ -250,7 +257,10 @@ typedef struct rt_render_opts {
                                  picture without its constant alpha byte, 3 bytes per pixel - a quarter less to move
                                  when the framebuffer is gathered from other GPUs (rt_assemble_frames_rgb8 puts the
                                  alpha byte back); no reference counterpart */
-    uint32_t _pad[2];
+    uint32_t frame_stride;    /* rt_render_frames: pixels from one frame's output to the next; 0 = packed (the pixels
+                                 one frame writes). Ranks whose shards differ in size use a common stride, so that the
+                                 gathered blocks have one layout */
+    uint32_t _pad;
 } rt_render_opts;
 #define RT_PIXEL_RGBA8 0u
 #define RT_PIXEL_RGB8 1u
@@ -315,6 +325,15 @@ int rt_assemble_frames_rgba8(rt_ctx* ctx, const uint8_t* gathered, uint32_t widt
 int rt_assemble_frames_rgb8(rt_ctx* ctx, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
                             uint32_t tile_h, uint32_t n_ranks, uint32_t n_frames, size_t rank_stride,
                             size_t frame_stride, uint8_t* images);
+
+/* The general form of the two above, for ranks that own unequal shares of the frame: owner is the table every rank
+ * rendered with (rt_shard.owner, `round` entries, values below n_ranks; rank r passed first = r, stride = round);
+ * NULL means one tile per rank per round, as above (round is ignored). A gathering rank spends time on the collective
+ * and on this call that the others do not, so it is given fewer tiles. pixel_format: how the gathered pixels are
+ * stored (RT_PIXEL_RGBA8 or RT_PIXEL_RGB8). No reference counterpart. */
+int rt_assemble_frames(rt_ctx* ctx, const uint8_t* gathered, uint32_t pixel_format, uint32_t width, uint32_t height,
+                       uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, const uint32_t* owner, uint32_t round,
+                       uint32_t n_frames, size_t rank_stride, size_t frame_stride, uint8_t* images);
 
 /* Counters of the most recent trace call made with params.collect_stats = 1. */
 int rt_get_stats(rt_ctx* ctx, rt_stats* stats);

@@ -62,7 +62,20 @@ class Params(C.Structure):
 
 
 class Shard(C.Structure):
-    _fields_ = [("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("first", C.c_uint32), ("stride", C.c_uint32)]
+    _fields_ = [("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("first", C.c_uint32), ("stride", C.c_uint32),
+                ("owner", C.POINTER(C.c_uint32))]
+
+    def __init__(self, tile_w=0, tile_h=0, first=0, stride=1, owner=None):
+        """owner: which rank traces each tile of a round (sequence of ints; its length becomes `stride`)."""
+        super().__init__(tile_w, tile_h, first, stride)
+        self._owner = None
+        if owner is not None:
+            self._owner = (C.c_uint32 * len(owner))(*[int(k) for k in owner])  # kept alive with the struct
+            self.owner = C.cast(self._owner, C.POINTER(C.c_uint32))
+            self.stride = len(owner)
+
+    def owner_list(self):
+        return list(self._owner) if self._owner is not None else None
 
 
 class Stats(C.Structure):

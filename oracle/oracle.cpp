@@ -844,6 +844,8 @@ inline V3 primary_dir(const CameraUniform& cam, const FrameConsts& fc, uint32_t 
 
 struct ShardMap {
     uint32_t tile_w, tile_h, first, stride, tiles_x, tiles_y, n_tiles, n_local;
+    std::vector<uint32_t> tiles;  // the frame tiles of this shard, in increasing order
+    uint32_t tile(uint32_t lt) const { return tiles[lt]; }
 };
 ShardMap shard_map(uint32_t w, uint32_t h, const rt_shard* sh) {
     ShardMap m;
@@ -854,7 +856,13 @@ ShardMap shard_map(uint32_t w, uint32_t h, const rt_shard* sh) {
     m.tiles_x = (w + m.tile_w - 1) / m.tile_w;
     m.tiles_y = (h + m.tile_h - 1) / m.tile_h;
     m.n_tiles = m.tiles_x * m.tiles_y;
-    m.n_local = m.first < m.n_tiles ? (m.n_tiles - m.first + m.stride - 1) / m.stride : 0;
+    // tile t belongs to the shard when it is tile `first` of its round of `stride` tiles, or, with an owner table,
+    // when the table names `first` at t's place in the round
+    for (uint32_t t = 0; t < m.n_tiles; ++t) {
+        const uint32_t o = t % m.stride;
+        if (sh && sh->owner ? sh->owner[o] == m.first : (t >= m.first && (t - m.first) % m.stride == 0)) m.tiles.push_back(t);
+    }
+    m.n_local = (uint32_t)m.tiles.size();
     return m;
 }
 
@@ -893,7 +901,7 @@ extern "C" void orc_trace_primary(const orc_scene* s, const rt_params* p, const 
         rt_stats& st_ = part[(size_t)k];
         for (uint64_t r = lo; r < hi; ++r) {
             uint32_t lt = (uint32_t)(r / m.tile_h), ly = (uint32_t)(r % m.tile_h);
-            uint32_t tile = m.first + lt * m.stride;
+            uint32_t tile = m.tile(lt);
             uint32_t ty = tile / m.tiles_x, tx = tile % m.tiles_x;
             uint32_t py = ty * m.tile_h + ly;
             for (uint32_t lx = 0; lx < m.tile_w; ++lx) {
@@ -1015,7 +1023,7 @@ extern "C" void orc_render(const orc_scene* s, const rt_params* p, const CameraU
         rt_stats& st_ = part[(size_t)k];
         for (uint64_t r = lo; r < hi; ++r) {
             uint32_t lt = (uint32_t)(r / m.tile_h), ly = (uint32_t)(r % m.tile_h);
-            uint32_t tile = m.first + lt * m.stride;
+            uint32_t tile = m.tile(lt);
             uint32_t ty = tile / m.tiles_x, tx = tile % m.tiles_x;
             uint32_t py = ty * m.tile_h + ly;
             for (uint32_t lx = 0; lx < m.tile_w; ++lx) {

@@ -57,7 +57,20 @@ class RtParams(C.Structure):
 
 
 class RtShard(C.Structure):
-    _fields_ = [("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("first", C.c_uint32), ("stride", C.c_uint32)]
+    _fields_ = [("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("first", C.c_uint32), ("stride", C.c_uint32),
+                ("owner", C.POINTER(C.c_uint32))]
+
+    def __init__(self, tile_w=0, tile_h=0, first=0, stride=1, owner=None):
+        """owner: which rank traces each tile of a round (sequence of ints; its length becomes `stride`)."""
+        super().__init__(tile_w, tile_h, first, stride)
+        self._owner = None
+        if owner is not None:
+            self._owner = (C.c_uint32 * len(owner))(*[int(k) for k in owner])  # kept alive with the struct
+            self.owner = C.cast(self._owner, C.POINTER(C.c_uint32))
+            self.stride = len(owner)
+
+    def owner_list(self):
+        return list(self._owner) if self._owner is not None else None
 
 
 class RtStats(C.Structure):
@@ -81,7 +94,7 @@ class RtTexture(C.Structure):
 
 class RtRenderOpts(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("shadows", C.c_uint32), ("debug_enabled", C.c_uint32),
-                ("debug_pixel", C.c_uint32 * 2), ("pixel_format", C.c_uint32), ("_pad", C.c_uint32 * 2)]
+                ("debug_pixel", C.c_uint32 * 2), ("pixel_format", C.c_uint32), ("frame_stride", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class RayDebugInfo(C.Structure):
@@ -123,6 +136,7 @@ PROTOTYPES = {
     "rt_assemble_tiles_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
     "rt_assemble_frames_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, C.c_size_t, C.c_size_t, _VP]),
     "rt_assemble_frames_rgb8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, C.c_size_t, C.c_size_t, _VP]),
+    "rt_assemble_frames": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, _VP, _U32, _U32, C.c_size_t, C.c_size_t, _VP]),
     "rt_render_frames": (_I, [_VP, _VP, _U32, _U32, _U32, C.POINTER(RtShard), C.POINTER(RtRenderOpts), _VP]),
     "rt_default_render_opts": (None, [C.POINTER(RtRenderOpts)]),
     "rt_set_materials": (_I, [_VP, _VP, _U32]),

@@ -152,37 +152,74 @@ __global__ void k_tri_pairs_watertight(const float* __restrict__ o, const float*
     out[i] = watertight(ld3(o + 3 * (size_t)r), ld3(d + 3 * (size_t)r), ld3(v), ld3(v + 3), ld3(v + 6));
 }
 
-template <class PIXEL>
-__global__ void k_assemble(const PIXEL* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w,
-                           uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks, size_t per_rank, size_t frame_stride,
-                           PIXEL* __restrict__ image) {
-    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= width || y >= height) return;
-    gathered += (size_t)blockIdx.z * frame_stride;
-    image += (size_t)blockIdx.z * width * height;
-    uint32_t tile = (y / tile_h) * tiles_x + (x / tile_w);
-    uint32_t rank = tile % n_ranks, lt = tile / n_ranks;
-    size_t src = (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h + (size_t)(y % tile_h) * tile_w + (x % tile_w);
-    image[(size_t)y * width + x] = gathered[src];
+// Which rank traced a frame tile, and where it sits in that rank's block: without a table rank = tile % n_ranks;
+// with one, three words per place o of a round: (rank, how many places of that rank come before o, places of that rank).
+struct AssemblePlan {
+    uint32_t n_ranks, round;
+    const uint32_t* places;
+};
+__device__ inline void locate_tile(const AssemblePlan& p, uint32_t tile, uint32_t& rank, uint32_t& lt) {
+    if (!p.places) {
+        rank = tile % p.n_ranks;
+        lt = tile / p.n_ranks;
+        return;
+    }
+    const uint32_t q = tile / p.round, o = tile - q * p.round;
+    rank = p.places[3 * o];
+    lt = q * p.places[3 * o + 2] + p.places[3 * o + 1];
 }
 
-// The same for layouts where 16 bytes of a row (PER pixels) never straddle a tile or the image edge: one workgroup per
-// tile, 16-byte loads and stores, the tile -> (rank, block) arithmetic once per workgroup.
-template <uint32_t PER>
-__global__ __launch_bounds__(256) void k_assemble_x16(const uint4* __restrict__ gathered, uint32_t width, uint32_t height,
-                                                      uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks,
+// One pixel per thread; RGB8: 3-byte pixels in, 4-byte pixels (alpha 255) out.
+template <class PIXEL, bool RGB8>
+__global__ void k_assemble(const void* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
+                           uint32_t tiles_x, AssemblePlan plan, size_t per_rank, size_t frame_stride, PIXEL* __restrict__ image) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    uint32_t rank, lt;
+    locate_tile(plan, (y / tile_h) * tiles_x + (x / tile_w), rank, lt);
+    const size_t src = (size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h +
+                       (size_t)(y % tile_h) * tile_w + (x % tile_w);
+    const size_t dst = (size_t)blockIdx.z * width * height + (size_t)y * width + x;
+    if constexpr (RGB8) {
+        const uint8_t* p = static_cast<const uint8_t*>(gathered) + 3 * src;
+        image[dst] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
+    } else {
+        image[dst] = static_cast<const PIXEL*>(gathered)[src];
+    }
+}
+
+// The same for layouts where 16 bytes of an output row (PER pixels) never straddle a tile or the image edge: one
+// workgroup per tile, a thread moves PER pixels at a time - 16 bytes in (12 for RGB8: three dwords), one 16-byte store
+// out - and the tile -> (rank, block) arithmetic is done once per workgroup.
+template <uint32_t PER, bool RGB8>
+__global__ __launch_bounds__(256) void k_assemble_x16(const uint32_t* __restrict__ gathered, uint32_t width, uint32_t height,
+                                                      uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x, AssemblePlan plan,
                                                       size_t per_rank, size_t frame_stride, uint4* __restrict__ image) {
-    const uint32_t tile = blockIdx.y * tiles_x + blockIdx.x;
-    const uint32_t rank = tile % n_ranks, lt = tile / n_ranks;
+    uint32_t rank, lt;
+    locate_tile(plan, blockIdx.y * tiles_x + blockIdx.x, rank, lt);
     const uint32_t x0 = blockIdx.x * tile_w, y0 = blockIdx.y * tile_h;
     const uint32_t vec_x = tile_w / PER;
     const uint32_t cols = min(vec_x, (width - x0) / PER), rows = min(tile_h, height - y0);
-    const uint4* src = gathered + ((size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h) / PER;
+    // first record of the tile, in vectors; RGB8: a multiple of 4 pixels is a whole number of dwords
+    const size_t first = ((size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h) / PER;
+    const uint32_t* src = gathered + first * (RGB8 ? 3 : 4);
     uint4* dst = image + ((size_t)blockIdx.z * width * height + (size_t)y0 * width + x0) / PER;
     const uint32_t n = vec_x * rows;
     for (uint32_t q = threadIdx.x; q < n; q += blockDim.x) {
         const uint32_t ly = q / vec_x, lq = q - ly * vec_x;
-        if (lq < cols) dst[(size_t)ly * (width / PER) + lq] = src[q];
+        if (lq >= cols) continue;
+        uint4 o;
+        if constexpr (RGB8) {
+            const uint32_t* p = src + 3 * (size_t)q;
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            o.x = (d0 & 0x00FFFFFFu) | 0xFF000000u;
+            o.y = (d0 >> 24) | ((d1 & 0x0000FFFFu) << 8) | 0xFF000000u;
+            o.z = (d1 >> 16) | ((d2 & 0x000000FFu) << 16) | 0xFF000000u;
+            o.w = (d2 >> 8) | 0xFF000000u;
+        } else {
+            o = reinterpret_cast<const uint4*>(src)[q];
+        }
+        dst[(size_t)ly * (width / PER) + lq] = o;
     }
 }
 
@@ -285,8 +322,30 @@ int update_box_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n) {
 
 int update_box_frame(rt_ctx* c, const CameraUniform* cam) { return update_box_frames(c, cam, 1); }
 
-ShardMap make_shard(uint32_t w, uint32_t h, const rt_shard* sh) {
+constexpr uint32_t MAX_OWNER_TABLE = 4096;
+
+// Device copy of `content`, uploaded the first time `key` is seen.
+int table_for(rt_ctx* c, std::vector<uint32_t>&& key, const std::vector<uint32_t>& content, const uint32_t** dev) {
+    for (rt_table* t : c->tables)
+        if (t->key == key) {
+            *dev = t->buf.as<uint32_t>();
+            return RT_OK;
+        }
+    if (c->tables.size() >= 256) return fail(c, RT_ERR_LIMIT, "more than 256 different owner tables in one context");
+    rt_table* t = new rt_table;
+    c->tables.push_back(t);
+    RT_HIP(c, t->buf.reserve(content.size() * sizeof(uint32_t)));
+    RT_HIP(c, hipMemcpy(t->buf.p, content.data(), content.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    t->key = std::move(key);  // only now: a failed upload must not be found again
+    *dev = t->buf.as<uint32_t>();
+    return RT_OK;
+}
+
+int make_shard(rt_ctx* c, uint32_t w, uint32_t h, const rt_shard* sh, ShardMap* out, const char* who) {
     ShardMap m;
+    memset(&m, 0, sizeof(m));
+    if (sh && (!sh->tile_w || !sh->tile_h || !sh->stride))
+        return fail(c, RT_ERR_INVALID, "%s: shard tile size and stride must be non-zero", who);
     m.tile_w = sh ? sh->tile_w : w;
     m.tile_h = sh ? sh->tile_h : h;
     m.first = sh ? sh->first : 0;
@@ -294,10 +353,33 @@ ShardMap make_shard(uint32_t w, uint32_t h, const rt_shard* sh) {
     m.tiles_x = (w + m.tile_w - 1) / m.tile_w;
     m.tiles_y = (h + m.tile_h - 1) / m.tile_h;
     m.n_tiles = m.tiles_x * m.tiles_y;
+    m.count = 1;
     m.n_local = m.first < m.n_tiles ? (m.n_tiles - m.first + m.stride - 1) / m.stride : 0;
+    if (sh && sh->owner) {
+        if (sh->stride > MAX_OWNER_TABLE)
+            return fail(c, RT_ERR_LIMIT, "%s: owner table of %u entries (max %u)", who, sh->stride, MAX_OWNER_TABLE);
+        std::vector<uint32_t> key{0u, sh->first, sh->stride}, mine;
+        key.insert(key.end(), sh->owner, sh->owner + sh->stride);
+        const uint32_t rem = m.n_tiles % m.stride;  // tiles of the last, partial round
+        uint32_t in_rem = 0;
+        for (uint32_t o = 0; o < sh->stride; ++o)
+            if (sh->owner[o] == sh->first) {
+                mine.push_back(o);
+                in_rem += o < rem ? 1u : 0u;
+            }
+        m.count = (uint32_t)mine.size();
+        m.n_local = m.n_tiles / m.stride * m.count + in_rem;
+        if (m.count == 0) {
+            m.count = 1;  // this rank owns nothing: an empty call
+            m.n_local = 0;
+        } else if (int r = table_for(c, std::move(key), mine, &m.offsets)) {
+            return r;
+        }
+    }
     m.sub_x = (m.tile_w + 7) / 8;
     m.sub_y = (m.tile_h + 7) / 8;
-    return m;
+    *out = m;
+    return RT_OK;
 }
 
 int zero_stats(rt_ctx* c) {
@@ -513,6 +595,10 @@ extern "C" void rt_destroy(rt_ctx* c) {
                       &c->in_o,      &c->in_d,      &c->stats,      &c->misc,      &c->tri_uv,    &c->texels,    &c->tc_start,  &c->tc_indices, &c->tc_pos, &c->dd_keys, &c->dd_keys2,
                       &c->dd_vals, &c->dd_vals2, &c->dd_flag, &c->dd_head, &c->dd_dup, &c->ref_cell, &c->tc_ref_cell};
     for (DevBuf* b : bufs) b->release();
+    for (rt_table* t : c->tables) {
+        t->buf.release();
+        delete t;
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
@@ -770,9 +856,8 @@ extern "C" int rt_trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t wi
     if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_trace_primary: no grid (call rt_build_grid or rt_set_grid_*)");
     if (!cam || !out_primary) return fail(c, RT_ERR_INVALID, "rt_trace_primary: NULL camera or output");
     if (!width || !height) return fail(c, RT_ERR_INVALID, "rt_trace_primary: empty frame");
-    if (shard && (!shard->tile_w || !shard->tile_h || !shard->stride))
-        return fail(c, RT_ERR_INVALID, "rt_trace_primary: shard tile size and stride must be non-zero");
-    const ShardMap m = make_shard(width, height, shard);
+    ShardMap m;
+    if (int r = make_shard(c, width, height, shard, &m, "rt_trace_primary")) return r;
     const size_t n_out = (size_t)m.n_local * m.tile_w * m.tile_h;
     if (n_out == 0) return RT_OK;
     const uint64_t blocks = (uint64_t)m.n_local * ((m.sub_x + 1) / 2) * ((m.sub_y + 1) / 2);  // 16x16 pixels each
@@ -867,132 +952,101 @@ extern "C" int rt_trace_rays(rt_ctx* c, const CameraUniform* cam, const float* o
     return RT_OK;
 }
 
-template <class PIXEL>
+// PIXEL: the output record (uint2 hit record, uint32_t RGBA8 pixel); RGB8: the gathered pixels are 3 bytes.
+// owner: the rt_shard.owner table the ranks rendered with (`round` entries), NULL = one tile each per round of n_ranks.
+template <class PIXEL, bool RGB8>
 static int assemble_tiles(rt_ctx* c, const void* gathered, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
-                          uint32_t n_ranks, size_t rank_stride, void* image, const char* who, uint32_t n_frames = 1,
-                          size_t frame_stride = 0) {
+                          uint32_t n_ranks, const uint32_t* owner, uint32_t round, size_t rank_stride, void* image, const char* who,
+                          uint32_t n_frames = 1, size_t frame_stride = 0) {
     if (int r = use(c)) return r;
     if (!gathered || !image || !width || !height || !tile_w || !tile_h || !n_ranks)
         return fail(c, RT_ERR_INVALID, "%s: NULL or zero argument", who);
     if (!is_device_ptr(gathered) || !is_device_ptr(image))
         return fail(c, RT_ERR_INVALID, "%s: both buffers must be device memory", who);
     const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
-    const size_t min_stride = (size_t)((tiles_x * tiles_y + n_ranks - 1) / n_ranks) * tile_w * tile_h;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    AssemblePlan plan;
+    memset(&plan, 0, sizeof(plan));
+    plan.n_ranks = plan.round = n_ranks;
+    uint32_t most = (n_tiles + n_ranks - 1) / n_ranks;  // tiles of the rank that owns most
+    if (owner) {
+        if (!round || round > MAX_OWNER_TABLE)
+            return fail(c, RT_ERR_LIMIT, "%s: owner table of %u entries (1 to %u)", who, round, MAX_OWNER_TABLE);
+        std::vector<uint32_t> key{1u, n_ranks, round}, places(3 * (size_t)round), count(n_ranks, 0u), tiles(n_ranks, 0u);
+        key.insert(key.end(), owner, owner + round);
+        const uint32_t rem = n_tiles % round;
+        for (uint32_t o = 0; o < round; ++o) {
+            if (owner[o] >= n_ranks) return fail(c, RT_ERR_INVALID, "%s: owner[%u] = %u, but there are %u ranks", who, o, owner[o], n_ranks);
+            places[3 * o] = owner[o];
+            places[3 * o + 1] = count[owner[o]]++;
+            tiles[owner[o]] += o < rem ? 1u : 0u;
+        }
+        most = 0;
+        for (uint32_t o = 0; o < round; ++o) places[3 * o + 2] = count[owner[o]];
+        for (uint32_t r = 0; r < n_ranks; ++r) most = std::max(most, n_tiles / round * count[r] + tiles[r]);
+        plan.round = round;
+        if (int r = table_for(c, std::move(key), places, &plan.places)) return r;
+    }
+    const size_t min_stride = (size_t)most * tile_w * tile_h;
     const size_t per_rank = rank_stride ? rank_stride : min_stride;
-    if (per_rank < min_stride) return fail(c, RT_ERR_INVALID, "%s: rank_stride smaller than one rank's block", who);
     if (n_frames == 0) return RT_OK;
     if (n_frames > 65535u) return fail(c, RT_ERR_LIMIT, "%s: more than 65535 frames", who);
-    if (n_frames > 1 && (frame_stride < min_stride || per_rank < (size_t)n_frames * min_stride))
-        return fail(c, RT_ERR_INVALID, "%s: frame_stride / rank_stride smaller than the frames they hold", who);
+    if (n_frames > 1 && !rank_stride) return fail(c, RT_ERR_INVALID, "%s: rank_stride is required", who);
+    if (per_rank < min_stride || (n_frames > 1 && (frame_stride < min_stride || per_rank < (size_t)n_frames * min_stride)))
+        return fail(c, RT_ERR_INVALID, "%s: frame_stride / rank_stride smaller than the blocks they hold", who);
     constexpr uint32_t PER = 16 / sizeof(PIXEL);
     const bool by_vectors = tile_w % PER == 0 && width % PER == 0 && per_rank % PER == 0 &&
                             (n_frames == 1 || frame_stride % PER == 0) && reinterpret_cast<uintptr_t>(gathered) % 16 == 0 &&
                             reinterpret_cast<uintptr_t>(image) % 16 == 0 && tiles_y <= 65535u &&
                             (uint64_t)tile_w * tile_h / PER <= 0xFFFFFFFFull;
     if (by_vectors)
-        hipLaunchKernelGGL(k_assemble_x16<PER>, dim3(tiles_x, tiles_y, n_frames), dim3(256), 0, c->stream,
-                           reinterpret_cast<const uint4*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks, per_rank,
+        hipLaunchKernelGGL((k_assemble_x16<PER, RGB8>), dim3(tiles_x, tiles_y, n_frames), dim3(256), 0, c->stream,
+                           reinterpret_cast<const uint32_t*>(gathered), width, height, tile_w, tile_h, tiles_x, plan, per_rank,
                            frame_stride, reinterpret_cast<uint4*>(image));
     else
-        hipLaunchKernelGGL(k_assemble<PIXEL>, dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream,
-                           reinterpret_cast<const PIXEL*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks, per_rank,
-                           frame_stride, reinterpret_cast<PIXEL*>(image));
+        hipLaunchKernelGGL((k_assemble<PIXEL, RGB8>), dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream, gathered,
+                           width, height, tile_w, tile_h, tiles_x, plan, per_rank, frame_stride, reinterpret_cast<PIXEL*>(image));
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
 
 extern "C" int rt_assemble_tiles(rt_ctx* c, const rt_hit* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
                                  uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, rt_hit* image) {
-    return assemble_tiles<uint2>(c, gathered, width, height, tile_w, tile_h, n_ranks, rank_stride, image, "rt_assemble_tiles");
+    return assemble_tiles<uint2, false>(c, gathered, width, height, tile_w, tile_h, n_ranks, nullptr, 0, rank_stride, image,
+                                        "rt_assemble_tiles");
 }
 
 extern "C" int rt_assemble_tiles_rgba8(rt_ctx* c, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
                                        uint32_t tile_h, uint32_t n_ranks, size_t rank_stride, uint8_t* image) {
-    return assemble_tiles<uint32_t>(c, gathered, width, height, tile_w, tile_h, n_ranks, rank_stride, image,
-                                    "rt_assemble_tiles_rgba8");
+    return assemble_tiles<uint32_t, false>(c, gathered, width, height, tile_w, tile_h, n_ranks, nullptr, 0, rank_stride, image,
+                                           "rt_assemble_tiles_rgba8");
+}
+
+extern "C" int rt_assemble_frames(rt_ctx* c, const uint8_t* gathered, uint32_t pixel_format, uint32_t width, uint32_t height,
+                                  uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, const uint32_t* owner, uint32_t round,
+                                  uint32_t n_frames, size_t rank_stride, size_t frame_stride, uint8_t* images) {
+    if (pixel_format == RT_PIXEL_RGB8)
+        return assemble_tiles<uint32_t, true>(c, gathered, width, height, tile_w, tile_h, n_ranks, owner, round, rank_stride, images,
+                                              "rt_assemble_frames", n_frames, frame_stride);
+    if (pixel_format == RT_PIXEL_RGBA8)
+        return assemble_tiles<uint32_t, false>(c, gathered, width, height, tile_w, tile_h, n_ranks, owner, round, rank_stride, images,
+                                               "rt_assemble_frames", n_frames, frame_stride);
+    if (int r = use(c)) return r;
+    return fail(c, RT_ERR_INVALID, "rt_assemble_frames: unknown pixel_format %u", pixel_format);
 }
 
 extern "C" int rt_assemble_frames_rgba8(rt_ctx* c, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
                                         uint32_t tile_h, uint32_t n_ranks, uint32_t n_frames, size_t rank_stride,
                                         size_t frame_stride, uint8_t* images) {
-    if (n_frames > 1 && !rank_stride) return fail(c, RT_ERR_INVALID, "rt_assemble_frames_rgba8: rank_stride is required");
-    return assemble_tiles<uint32_t>(c, gathered, width, height, tile_w, tile_h, n_ranks, rank_stride, images,
-                                    "rt_assemble_frames_rgba8", n_frames, frame_stride);
-}
-
-// 3-byte pixels in, 4-byte pixels (alpha 255) out.
-__global__ void k_assemble_rgb8(const uint8_t* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w,
-                                uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks, size_t per_rank, size_t frame_stride,
-                                uint32_t* __restrict__ image) {
-    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= width || y >= height) return;
-    uint32_t tile = (y / tile_h) * tiles_x + (x / tile_w);
-    uint32_t rank = tile % n_ranks, lt = tile / n_ranks;
-    size_t src = (size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h +
-                 (size_t)(y % tile_h) * tile_w + (x % tile_w);
-    const uint8_t* p = gathered + 3 * src;
-    image[(size_t)blockIdx.z * width * height + (size_t)y * width + x] =
-        (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | 0xFF000000u;
-}
-
-// The same for layouts where four pixels of a row never straddle a tile or the image edge (tile_w and width multiples of
-// 4, strides multiples of 4 pixels, buffers 16-byte aligned): one workgroup per tile, a thread moves four pixels at a
-// time - three dwords in, one 16-byte store out - and the tile -> (rank, block) arithmetic is done once per workgroup.
-__global__ __launch_bounds__(256) void k_assemble_rgb8_x4(const uint32_t* __restrict__ gathered, uint32_t width, uint32_t height,
-                                                          uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x, uint32_t n_ranks,
-                                                          size_t per_rank, size_t frame_stride, uint4* __restrict__ image) {
-    const uint32_t tile = blockIdx.y * tiles_x + blockIdx.x;
-    const uint32_t rank = tile % n_ranks, lt = tile / n_ranks;
-    const uint32_t x0 = blockIdx.x * tile_w, y0 = blockIdx.y * tile_h;
-    const uint32_t quads_x = tile_w / 4;
-    const uint32_t cols = min(quads_x, (width - x0) / 4), rows = min(tile_h, height - y0);
-    // pixel index of the tile's first record; a multiple of 4, so 3 bytes * index is a whole number of dwords
-    const size_t first = (size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h;
-    const uint32_t* src = gathered + first / 4 * 3;
-    uint4* dst = image + ((size_t)blockIdx.z * width * height + (size_t)y0 * width + x0) / 4;
-    const uint32_t n = quads_x * rows;
-    for (uint32_t q = threadIdx.x; q < n; q += blockDim.x) {
-        const uint32_t ly = q / quads_x, lq = q - ly * quads_x;
-        if (lq >= cols) continue;
-        const uint32_t* p = src + 3 * (size_t)q;
-        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-        uint4 o;
-        o.x = (d0 & 0x00FFFFFFu) | 0xFF000000u;
-        o.y = (d0 >> 24) | ((d1 & 0x0000FFFFu) << 8) | 0xFF000000u;
-        o.z = (d1 >> 16) | ((d2 & 0x000000FFu) << 16) | 0xFF000000u;
-        o.w = (d2 >> 8) | 0xFF000000u;
-        dst[(size_t)ly * (width / 4) + lq] = o;
-    }
+    return assemble_tiles<uint32_t, false>(c, gathered, width, height, tile_w, tile_h, n_ranks, nullptr, 0, rank_stride, images,
+                                           "rt_assemble_frames_rgba8", n_frames, frame_stride);
 }
 
 extern "C" int rt_assemble_frames_rgb8(rt_ctx* c, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,
                                        uint32_t tile_h, uint32_t n_ranks, uint32_t n_frames, size_t rank_stride,
                                        size_t frame_stride, uint8_t* images) {
-    const char* who = "rt_assemble_frames_rgb8";
-    if (int r = use(c)) return r;
-    if (!gathered || !images || !width || !height || !tile_w || !tile_h || !n_ranks)
-        return fail(c, RT_ERR_INVALID, "%s: NULL or zero argument", who);
-    if (!is_device_ptr(gathered) || !is_device_ptr(images))
-        return fail(c, RT_ERR_INVALID, "%s: both buffers must be device memory", who);
-    const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
-    const size_t min_stride = (size_t)((tiles_x * tiles_y + n_ranks - 1) / n_ranks) * tile_w * tile_h;
-    const size_t per_rank = rank_stride ? rank_stride : min_stride;
-    if (n_frames == 0) return RT_OK;
-    if (n_frames > 65535u) return fail(c, RT_ERR_LIMIT, "%s: more than 65535 frames", who);
-    if (per_rank < min_stride || (n_frames > 1 && (frame_stride < min_stride || per_rank < (size_t)n_frames * min_stride)))
-        return fail(c, RT_ERR_INVALID, "%s: frame_stride / rank_stride smaller than the frames they hold", who);
-    const bool by_fours = tile_w % 4 == 0 && width % 4 == 0 && per_rank % 4 == 0 && (n_frames == 1 || frame_stride % 4 == 0) &&
-                          reinterpret_cast<uintptr_t>(gathered) % 16 == 0 && reinterpret_cast<uintptr_t>(images) % 16 == 0 &&
-                          tiles_y <= 65535u && (uint64_t)tile_w * tile_h / 4 <= 0xFFFFFFFFull;
-    if (by_fours)
-        hipLaunchKernelGGL(k_assemble_rgb8_x4, dim3(tiles_x, tiles_y, n_frames), dim3(256), 0, c->stream,
-                           reinterpret_cast<const uint32_t*>(gathered), width, height, tile_w, tile_h, tiles_x, n_ranks, per_rank,
-                           frame_stride, reinterpret_cast<uint4*>(images));
-    else
-        hipLaunchKernelGGL(k_assemble_rgb8, dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream, gathered, width,
-                           height, tile_w, tile_h, tiles_x, n_ranks, per_rank, frame_stride, reinterpret_cast<uint32_t*>(images));
-    RT_HIP(c, hipGetLastError());
-    return RT_OK;
+    return assemble_tiles<uint32_t, true>(c, gathered, width, height, tile_w, tile_h, n_ranks, nullptr, 0, rank_stride, images,
+                                          "rt_assemble_frames_rgb8", n_frames, frame_stride);
 }
 
 // ================================================================== skinning
@@ -1132,19 +1186,21 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
     if (n_frames == 0) return RT_OK;
     if (n_frames > MAX_FRAMES_PER_LAUNCH)
         return fail(c, RT_ERR_LIMIT, "rt_render_frames: %u frames in one call (max %u)", n_frames, MAX_FRAMES_PER_LAUNCH);
-    if (shard && (!shard->tile_w || !shard->tile_h || !shard->stride))
-        return fail(c, RT_ERR_INVALID, "rt_render: shard tile size and stride must be non-zero");
     rt_render_opts o;
     rt_default_render_opts(&o);
     if (opts) o = *opts;
-    const ShardMap m = make_shard(width, height, shard);
+    ShardMap m;
+    if (int r = make_shard(c, width, height, shard, &m, "rt_render")) return r;
     const size_t n_frame = (size_t)m.n_local * m.tile_w * m.tile_h, n_out = n_frame * n_frames;
     if (n_out == 0) return RT_OK;
     const uint64_t blocks = (uint64_t)m.n_local * ((m.sub_x + 1) / 2) * ((m.sub_y + 1) / 2);
     if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "rt_render: frame too large");
     if (o.pixel_format != RT_PIXEL_RGBA8 && o.pixel_format != RT_PIXEL_RGB8)
         return fail(c, RT_ERR_INVALID, "rt_render: unknown pixel_format %u", o.pixel_format);
-    const size_t out_bytes = n_out * (o.pixel_format == RT_PIXEL_RGB8 ? 3 : 4);
+    if (o.frame_stride && o.frame_stride < n_frame)
+        return fail(c, RT_ERR_INVALID, "rt_render_frames: frame_stride %u smaller than the %zu pixels of a frame", o.frame_stride, n_frame);
+    const size_t stride = o.frame_stride ? o.frame_stride : n_frame;
+    const size_t out_bytes = ((n_frames - 1) * stride + n_frame) * (o.pixel_format == RT_PIXEL_RGB8 ? 3 : 4);
     const bool host_out = !is_device_ptr(out_rgba8);
     uint32_t* out = reinterpret_cast<uint32_t*>(out_rgba8);
     if (host_out) {
@@ -1175,7 +1231,7 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
     sh.debug_y = o.debug_pixel[1];
     sh.rgb8 = o.pixel_format == RT_PIXEL_RGB8 ? 1u : 0u;
     sh.box_frame_stride = c->nb * 4;
-    sh.frame_pixels = n_frame;
+    sh.frame_pixels = stride;
     unsigned long long* st = stats ? c->stats.as<unsigned long long>() : nullptr;
     const dim3 grid((uint32_t)blocks, n_frames);
     const bool wgsl = c->params.wgsl_compat != 0, has_boxes = s.nb != 0;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/rt_mi355.h"
 #include "rt_trace.hpp"
@@ -47,8 +48,16 @@ struct DevBuf {
 
 }  // namespace rt
 
+// A small table uploaded once and kept for the context's lifetime (kernels in flight on any stream may be reading
+// it): the places of a shard's tiles in a round, or the assemble kernels' owner records. Found again by its key.
+struct rt_table {
+    std::vector<uint32_t> key;
+    rt::DevBuf buf;
+};
+
 struct rt_ctx {
     int device = 0;
+    std::vector<rt_table*> tables;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream in use (own_stream or the caller's)
     rt_params params;

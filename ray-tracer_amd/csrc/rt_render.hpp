@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(DevScene s, Dev
     if (lt >= m.n_local) return;
     const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
     const uint32_t lx = sub_x * 8 + (lane & 7), ly = sub_y * 8 + (lane >> 3);
-    const uint32_t tile = m.first + lt * m.stride;
+    const uint32_t tile = shard_tile(m, lt);
     const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
     const bool in_tile = lx < m.tile_w && ly < m.tile_h;
     const bool live = in_tile && px < f.width && py < f.height;

@@ -82,9 +82,17 @@ struct DevFrame {
 };
 
 struct ShardMap {
-    uint32_t tile_w, tile_h, first, stride, tiles_x, tiles_y, n_tiles, n_local;
+    uint32_t tile_w, tile_h, first, stride, count, tiles_x, tiles_y, n_tiles, n_local;
     uint32_t sub_x, sub_y;  // 8x8 sub-tiles per tile
+    const uint32_t* offsets;  // owner table given: the `count` places in a round of `stride` tiles this call traces
 };
+
+// Frame tile of local tile lt: tile `first` of every round of `stride` tiles, or the tiles at `offsets` of every round.
+__device__ inline uint32_t shard_tile(const ShardMap& m, uint32_t lt) {
+    if (!m.offsets) return m.first + lt * m.stride;
+    const uint32_t round = lt / m.count;
+    return round * m.stride + m.offsets[lt - round * m.count];
+}
 
 struct Counters {
     uint32_t cells, tri, box, steps;
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
     if (lt >= m.n_local) return;  // whole workgroup
     const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
     const uint32_t lx = sub_x * 8 + (lane & 7), ly = sub_y * 8 + (lane >> 3);
-    const uint32_t tile = m.first + lt * m.stride;
+    const uint32_t tile = shard_tile(m, lt);
     const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
     const bool in_tile = lx < m.tile_w && ly < m.tile_h;
     const bool live = in_tile && px < f.width && py < f.height;

@@ -109,7 +109,13 @@ def shard_pixels(width, height, shard):
     tiles_x = -(-width // shard.tile_w)
     tiles_y = -(-height // shard.tile_h)
     n_tiles = tiles_x * tiles_y
-    n_local = -(-(n_tiles - shard.first) // shard.stride) if shard.first < n_tiles else 0
+    owner = shard.owner_list()
+    if owner is not None:
+        rem = n_tiles % shard.stride
+        n_local = (n_tiles // shard.stride * sum(1 for k in owner if k == shard.first)
+                   + sum(1 for k in owner[:rem] if k == shard.first))
+    else:
+        n_local = -(-(n_tiles - shard.first) // shard.stride) if shard.first < n_tiles else 0
     return n_local * shard.tile_w * shard.tile_h
 
 
@@ -312,10 +318,12 @@ class TraceCore:
                                    _ptr(out)))
         return out
 
-    def render_frames(self, cams, width, height, shard=None, max_bounces=8, shadows=False, out=None, rgb8=False):
+    def render_frames(self, cams, width, height, shard=None, max_bounces=8, shadows=False, out=None, rgb8=False,
+                      frame_stride=0):
         """Up to 16 consecutive frames in one launch: (n_frames, n_pixels, 4) uint8, or (n_frames, n_pixels, 3)
-        with rgb8 (no alpha byte). `cams`: sequence of CameraUniform."""
-        n = shard_pixels(width, height, shard)
+        with rgb8 (no alpha byte). `cams`: sequence of CameraUniform. frame_stride: pixels between frames in `out`
+        when that is more than one frame writes (0 = packed)."""
+        n = frame_stride or shard_pixels(width, height, shard)
         arr = (CameraUniform * len(cams))()
         for j, cam in enumerate(cams):
             C.memmove(C.byref(arr, j * C.sizeof(CameraUniform)), C.byref(cam), C.sizeof(CameraUniform))
@@ -324,6 +332,7 @@ class TraceCore:
         o = RtRenderOpts()
         self._L.rt_default_render_opts(C.byref(o))
         o.max_bounces, o.shadows, o.pixel_format = max_bounces, 1 if shadows else 0, 1 if rgb8 else 0
+        o.frame_stride = frame_stride
         self._ck(self._L.rt_render_frames(self._h, arr, len(cams), width, height, _ref(shard, RtShard), C.byref(o), _ptr(out)))
         return out
 
@@ -336,6 +345,14 @@ class TraceCore:
                              images):
         self._ck(self._L.rt_assemble_frames_rgb8(self._h, _ptr(gathered), width, height, tile_w, tile_h, n_ranks, n_frames,
                                                  rank_stride, frame_stride, _ptr(images)))
+
+    def assemble_frames(self, gathered, rgb8, width, height, tile_w, tile_h, n_ranks, owner, n_frames, rank_stride,
+                        frame_stride, images):
+        """owner: the table the ranks rendered with (RtShard(owner=...)), None = one tile each per round."""
+        tab = (C.c_uint32 * len(owner))(*[int(k) for k in owner]) if owner is not None else None
+        self._ck(self._L.rt_assemble_frames(self._h, _ptr(gathered), 1 if rgb8 else 0, width, height, tile_w, tile_h, n_ranks,
+                                            tab, len(owner) if owner is not None else 0, n_frames, rank_stride, frame_stride,
+                                            _ptr(images)))
 
     def debug_pixel(self, cam, width, height, px, py):
         info = RayDebugInfo()

@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import RtShard
+from .host import shard_pixels
 
 
 def n_tiles(width, height, tile_w, tile_h):
@@ -40,6 +41,30 @@ def n_tiles(width, height, tile_w, tile_h):
 def per_rank_pixels(width, height, tile_w, tile_h, world):
     """Records in one rank's block of the gather: ceil(n_tiles / world) whole tiles."""
     return -(-n_tiles(width, height, tile_w, tile_h) // world) * tile_w * tile_h
+
+
+def owner_table(weights):
+    """Which rank traces each tile of a round, for ranks that own weights[r] tiles of every sum(weights): the tiles are
+    dealt round-robin among the ranks that still have some to take, so every rank's tiles are spread over the round
+    (and with it over the frame) as evenly as its weight allows. [3, 4, 4] -> 0 1 2 0 1 2 0 1 2 1 2."""
+    left = [int(k) for k in weights]
+    table = []
+    while any(left):
+        for r, k in enumerate(left):
+            if k:
+                table.append(r)
+                left[r] -= 1
+    return table
+
+
+def gatherer_weights(world, resolution=64, lag=3):
+    """Tiles per round that leave the gathering rank (0) `lag` parts in `resolution` short of an equal share:
+    [K - lag, K, K, ...] with K = resolution / world. On a 1080p frame of the bundled model the gathering rank spends
+    about 5 % of a single GPU's frame time on assembling (while it renders), which the others do not."""
+    if world < 2:
+        return None
+    k = max(lag + 1, round(resolution / world))
+    return [k - lag] + [k] * (world - 1)
 
 
 def broadcast_scene(boxes, tris, device, src=0):
@@ -114,7 +139,7 @@ class FrameSharder:
                  valid until that many further frames have been started."""
 
     def __init__(self, core, width, height, tile_w=64, tile_h=64, rank=None, world=None, device="cuda", shadow=True,
-                 mode="hits", frames_in_flight=1, max_bounces=8, collective=None):
+                 mode="hits", frames_in_flight=1, max_bounces=8, collective=None, weights=None):
         if mode not in ("hits", "rgba"):
             raise ValueError("mode must be 'hits' or 'rgba'")
         self.core, self.width, self.height, self.tile_w, self.tile_h = core, width, height, tile_w, tile_h
@@ -124,8 +149,22 @@ class FrameSharder:
         # the gather is skipped for a lone rank unless asked for (a one-rank process group exercises the backend)
         self.collective = self.world > 1 if collective is None else bool(collective)
         self.device = device
-        self.shard = RtShard(tile_w, tile_h, self.rank, self.world)
-        self.per_rank = per_rank_pixels(width, height, tile_w, tile_h, self.world)
+        # weights[r]: tiles rank r owns out of every sum(weights) ("rgba" mode), dealt as owner_table says. Rank 0 also
+        # gathers and assembles, so it is given less to render than the others; None = one tile each.
+        self.weights = None if weights is None else [int(k) for k in weights]
+        self.owner = None
+        if self.weights is not None:
+            if mode != "rgba":
+                raise ValueError("weights need the picture path: mode must be 'rgba'")
+            if len(self.weights) != self.world or min(self.weights) < 1:
+                raise ValueError("weights: one positive integer per rank")
+            self.owner = owner_table(self.weights)
+            shards = [RtShard(tile_w, tile_h, r, owner=self.owner) for r in range(self.world)]
+            self.shard = shards[self.rank]
+            self.per_rank = max(shard_pixels(width, height, s) for s in shards)
+        else:
+            self.shard = RtShard(tile_w, tile_h, self.rank, self.world)
+            self.per_rank = per_rank_pixels(width, height, tile_w, tile_h, self.world)
         self.blocks = 2 if shadow else 1
         # Trace kernels, the gather and the assemble kernel of a frame share one in-order stream: the collective
         # only waits for work queued on torch's current stream, and makes that stream wait for its completion.
@@ -195,7 +234,8 @@ class FrameSharder:
         rgb8 = self.wire_bytes == 3
         for j in range(0, g, 16):  # one launch renders up to 16 frames
             self.core.render_frames(cams[j:j + 16], self.width, self.height, shard=self.shard, max_bounces=self.max_bounces,
-                                    shadows=self.shadow, out=slot.local[j:min(g, j + 16)], rgb8=rgb8)
+                                    shadows=self.shadow, out=slot.local[j:min(g, j + 16)], rgb8=rgb8,
+                                    frame_stride=self.per_rank)
         if self.collective:
             if g not in slot.views:  # tensor views are not free to make: once per group length
                 slot.views[g] = (slot.local[:g], [slot.packed[r, :g] for r in range(self.world)] if self.rank == 0 else None)
@@ -204,9 +244,8 @@ class FrameSharder:
         if self.rank != 0:
             return None
         src = slot.packed if self.collective else slot.local.unsqueeze(0)
-        assemble = self.core.assemble_frames_rgb8 if rgb8 else self.core.assemble_frames_rgba8
-        assemble(src, self.width, self.height, self.tile_w, self.tile_h, self.world, g, self.group * self.per_rank,
-                 self.per_rank, slot.images[:g])
+        self.core.assemble_frames(src, rgb8, self.width, self.height, self.tile_w, self.tile_h, self.world, self.owner, g,
+                                  self.group * self.per_rank, self.per_rank, slot.images[:g])
         return slot.images[:g]
 
     def _trace(self, cam, slot):
@@ -217,8 +256,8 @@ class FrameSharder:
             return None
         src = slot.packed if self.collective else slot.local.unsqueeze(0)
         if self.mode == "rgba":
-            self.core.assemble_tiles_rgba8(src[0], self.width, self.height, self.tile_w, self.tile_h, self.world,
-                                           slot.image, rank_stride=self.per_rank)
+            self.core.assemble_frames(src[0], False, self.width, self.height, self.tile_w, self.tile_h, self.world,
+                                      self.owner, 1, self.per_rank, self.per_rank, slot.image)
             return slot.image
         for b in range(self.blocks):
             self.core.assemble_tiles(src[0, b], self.width, self.height, self.tile_w, self.tile_h, self.world,

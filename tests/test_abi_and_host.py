@@ -46,7 +46,7 @@ def test_wire_struct_sizes(rt):
     # sizes asserted in include/rt_types.h (reference src/types.rs, src/grid.rs)
     assert C.sizeof(rt.CameraUniform) == 80 and C.sizeof(rt.GridMetadata) == 96 and C.sizeof(rt.RayDebugInfo) == 80
     assert rt.BOX_DTYPE.itemsize == 96 and rt.TRIANGLE_DTYPE.itemsize == 80 and rt.HIT_DTYPE.itemsize == 8
-    assert C.sizeof(rt.RtStats) == 56 and C.sizeof(rt.RtShard) == 16 and C.sizeof(rt.RtParams) == 52
+    assert C.sizeof(rt.RtStats) == 56 and C.sizeof(rt.RtShard) == 24 and C.sizeof(rt.RtParams) == 52
 
 
 def test_default_params_are_the_reference_constants(rt):
@@ -75,6 +75,18 @@ def test_shard_pixels_matches_oracle(rt, ob):
         for r in range(n):
             assert rt.shard_pixels(w, h, rt.RtShard(tw, th, r, n)) == ob.shard_pixels(w, h, ob.Shard(tw, th, r, n))
     assert rt.shard_pixels(33, 7, None) == 231
+    # unequal shares through an owner table; together the ranks cover every tile once
+    from ray_tracer_amd import sharding
+    assert sharding.owner_table([3, 4, 4]) == [0, 1, 2, 0, 1, 2, 0, 1, 2, 1, 2]
+    for (w, h, tw, th, weights) in ((1920, 1080, 32, 32, (5, 8, 8, 8, 8, 8, 8, 8)), (150, 85, 32, 16, (2, 3, 3)), (70, 45, 16, 8, (1, 5))):
+        owner = sharding.owner_table(weights)
+        assert len(owner) == sum(weights) and all(owner.count(r) == k for r, k in enumerate(weights))
+        total = 0
+        for r in range(len(weights)):
+            a = rt.shard_pixels(w, h, rt.RtShard(tw, th, r, owner=owner))
+            assert a == ob.shard_pixels(w, h, ob.Shard(tw, th, r, owner=owner))
+            total += a
+        assert total == -(-w // tw) * -(-h // th) * tw * th
 
 
 def test_no_gpu_means_error_not_fallback(rt):

@@ -212,7 +212,7 @@ def test_grid_rebuild_after_vertex_update(core, ob, phoenix_xyz9):
 
 def check_frame(core, ob, scene, cam, w, h, shard=None, what=""):
     p, s = core.trace_primary(cam, w, h, shard=shard)
-    oshard = ob.Shard(shard.tile_w, shard.tile_h, shard.first, shard.stride) if shard is not None else None
+    oshard = ob.Shard(shard.tile_w, shard.tile_h, shard.first, shard.stride, shard.owner_list()) if shard is not None else None
     op, os_, st = ob.trace_primary(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params), shard=oshard)
     assert_hits_equal(p, op, what + " primary")
     assert_hits_equal(s, os_, what + " shadow")

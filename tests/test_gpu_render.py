@@ -29,7 +29,7 @@ def check(core, ob, scene, cam, w, h, materials=None, what="", **kw):
     okw = dict(kw)
     if "shard" in okw and okw["shard"] is not None:
         s = okw["shard"]
-        okw["shard"] = ob.Shard(s.tile_w, s.tile_h, s.first, s.stride)
+        okw["shard"] = ob.Shard(s.tile_w, s.tile_h, s.first, s.stride, s.owner_list())
     want, st = ob.render(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params), materials=materials, **okw)
     bad = np.flatnonzero((got != want).any(axis=1))
     assert bad.size == 0, f"{what}: {bad.size} pixels differ, first {bad[:5]}: {got[bad[:5]]} vs {want[bad[:5]]}"
@@ -286,15 +286,19 @@ def test_alpha_rules_hit_records_and_picture(core, ob, rt, car_xyz9):
     core.set_materials(None)
 
 
-def _scatter(packed, w, h, tw, th, world, n_frames, alpha):
-    """numpy restatement of the assemble kernels: packed is [rank][frame][record][bytes]."""
+def _scatter(packed, w, h, tw, th, world, n_frames, alpha, owner=None):
+    """numpy restatement of the assemble kernels: packed is [rank][frame][record][bytes]; owner: the rank of every
+    tile of a round (None: one tile each, in rank order)."""
+    owner = owner or list(range(world))
     tx, ty = -(-w // tw), -(-h // th)
     per = packed.shape[-1]
     out = np.zeros((n_frames, h, w, per if alpha is None else 4), packed.dtype)
     if alpha is not None:
         out[..., 3] = alpha
     for tile in range(tx * ty):
-        r, lt = tile % world, tile // world
+        o = tile % len(owner)
+        r = owner[o]
+        lt = tile // len(owner) * owner.count(r) + owner[:o].count(r)
         x0, y0 = (tile % tx) * tw, (tile // tx) * th
         hh, ww = min(th, h - y0), min(tw, w - x0)
         blk = packed[r, :, lt * tw * th:(lt + 1) * tw * th].reshape(n_frames, th, tw, per)
@@ -329,6 +333,21 @@ def test_assemble_kernels_equal_a_numpy_scatter(core, rt, w, h, tw, th, world):
         core.sync()
         want = _scatter(packed, w, h, tw, th, world, n_frames, 255)
         assert np.array_equal(images.cpu().numpy(), want), f"{per}-byte pictures, {w}x{h} tiles {tw}x{th} over {world}"
+    # unequal shares: the first rank owns 3 tiles of every round, the others 4 each
+    owner = sharding.owner_table([3] + [4] * (world - 1))
+    shards = [rt.RtShard(tw, th, r, owner=owner) for r in range(world)]
+    per_w = max(rt.shard_pixels(w, h, s) for s in shards)
+    for per in (3, 4):
+        packed = rng.integers(0, 256, (world, n_frames, per_w, per)).astype(np.uint8)
+        if per == 4:
+            packed[..., 3] = 255
+        dev = torch.from_numpy(packed).cuda()
+        images = torch.zeros((n_frames, h * w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        core.assemble_frames(dev, per == 3, w, h, tw, th, world, owner, n_frames, n_frames * per_w, per_w, images)
+        core.sync()
+        want = _scatter(packed, w, h, tw, th, world, n_frames, 255, owner)
+        assert np.array_equal(images.cpu().numpy(), want), f"{per}-byte pictures with owner table {owner}"
     # hit records (8 bytes), one frame, and the one-frame RGBA8 entry point
     hits = rng.integers(-2**31, 2**31 - 1, (world, 1, per_rank, 2)).astype(np.int32)
     dev = torch.from_numpy(hits).cuda()
@@ -344,3 +363,48 @@ def test_assemble_kernels_equal_a_numpy_scatter(core, rt, w, h, tw, th, world):
     core.assemble_tiles_rgba8(dev, w, h, tw, th, world, image, rank_stride=per_rank)
     core.sync()
     assert np.array_equal(image.cpu().numpy(), _scatter(pic, w, h, tw, th, world, 1, None)[0])
+
+
+def test_unequal_shares_render_and_assemble(core, ob, rt, car_xyz9):
+    """Ranks that own different numbers of tiles per round (rt_shard.owner): each rank's packed output equals the
+    oracle's for the same shard - hit records and the picture - and three frames rendered with a common frame stride,
+    assembled with the counts, equal the whole pictures."""
+    import torch
+    tris = rt.triangles_from_xyz9(car_xyz9)
+    core.set_scene(None, tris)
+    core.set_materials(None)
+    core.build_grid()
+    scene = ob.Scene(None, ob.triangles_from_xyz9(car_xyz9))
+    w, h, tw, th = 200, 120, 32, 16
+    from ray_tracer_amd import sharding
+    counts = [1, 3, 2]
+    owner = sharding.owner_table(counts)
+    cams = [rt.Camera.for_scene("gltf").to_uniform(0.0, float(h)), rt.Camera((0, 150, 50), 1.0, -0.4).to_uniform(0.0, float(h)),
+            rt.Camera((150, 120, 250), 3.4, -0.3).to_uniform(0.0, float(h))]
+    shards = [rt.RtShard(tw, th, r, owner=owner) for r in range(len(counts))]
+    per = max(rt.shard_pixels(w, h, s) for s in shards)
+    packed = torch.zeros((len(counts), len(cams), per, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for r, s in enumerate(shards):
+        check(core, ob, scene, cams[0], w, h, what=f"rank {r} of counts {counts}", shard=s, max_bounces=2)
+        p, sdw = core.trace_primary(cams[0], w, h, shard=s, shadow=True)
+        op, osd, _ = ob.trace_primary(scene, ocam(ob, cams[0]), w, h, shard=ob.Shard(tw, th, s.first, s.stride, owner),
+                                      params=oparams(ob, core.params), n_threads=4)
+        assert np.array_equal(p["id"], op["id"]) and np.array_equal(p["t"].view(np.uint32), op["t"].view(np.uint32))
+        assert np.array_equal(sdw["id"], osd["id"]) and np.array_equal(sdw["t"].view(np.uint32), osd["t"].view(np.uint32))
+        core.render_frames(cams, w, h, shard=s, max_bounces=1, out=packed[r], rgb8=True, frame_stride=per)
+    images = torch.zeros((len(cams), h * w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    core.assemble_frames(packed, True, w, h, tw, th, len(counts), owner, len(cams), len(cams) * per, per, images)
+    core.sync()
+    for j, cam in enumerate(cams):
+        want, _ = ob.render(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params), max_bounces=1)
+        assert np.array_equal(images[j].cpu().numpy(), want), f"frame {j}"
+    # a rank the table does not name renders nothing; a table that names a rank beyond n_ranks, or a frame stride
+    # smaller than a frame, is refused
+    assert rt.shard_pixels(w, h, rt.RtShard(tw, th, 7, owner=owner)) == 0
+    core.render_frames(cams, w, h, shard=rt.RtShard(tw, th, 7, owner=owner), out=packed[0], rgb8=True)
+    with pytest.raises(rt.RtError):
+        core.assemble_frames(packed, True, w, h, tw, th, 2, owner, len(cams), len(cams) * per, per, images)
+    with pytest.raises(rt.RtError):
+        core.render_frames(cams, w, h, shard=shards[1], out=packed[1], rgb8=True, frame_stride=per // 4)

@@ -23,19 +23,21 @@ class OracleCore:
         self.ob, self.scene = ob, scene
 
     def trace_primary(self, cam, width, height, shard=None, shadow=True, out_primary=None, out_shadow=None):
-        osh = self.ob.Shard(shard.tile_w, shard.tile_h, shard.first, shard.stride) if shard is not None else None
+        osh = self.ob.Shard(shard.tile_w, shard.tile_h, shard.first, shard.stride, shard.owner_list()) if shard is not None else None
         p, s, _ = self.ob.trace_primary(self.scene, cam, width, height, shard=osh, shadow=shadow, n_threads=2)
         out_primary[:len(p)] = torch.from_numpy(p.view(np.int32).reshape(-1, 2))
         if shadow:
             out_shadow[:len(s)] = torch.from_numpy(s.view(np.int32).reshape(-1, 2))
 
     def render(self, cam, width, height, shard=None, max_bounces=8, shadows=False, out=None):
-        osh = self.ob.Shard(shard.tile_w, shard.tile_h, shard.first, shard.stride) if shard is not None else None
+        osh = self.ob.Shard(shard.tile_w, shard.tile_h, shard.first, shard.stride, shard.owner_list()) if shard is not None else None
         img, _ = self.ob.render(self.scene, cam, width, height, shard=osh, max_bounces=max_bounces, shadows=shadows,
                                 n_threads=2)
         out[:len(img)] = torch.from_numpy(img)
 
-    def render_frames(self, cams, width, height, shard=None, max_bounces=8, shadows=False, out=None, rgb8=False):
+    def render_frames(self, cams, width, height, shard=None, max_bounces=8, shadows=False, out=None, rgb8=False,
+                      frame_stride=0):
+        assert frame_stride in (0, out.shape[1])  # frames are frame_stride pixels apart in `out`
         for j, cam in enumerate(cams):
             if rgb8:
                 tmp = torch.zeros((out.shape[1], 4), dtype=torch.uint8)
@@ -59,6 +61,19 @@ class OracleCore:
         for j in range(n_frames):
             self._assemble(flat[j * frame_stride:], width, height, tile_w, tile_h, n_ranks, images[j], rank_stride, torch.uint8, 4)
 
+    def assemble_frames(self, gathered, rgb8, width, height, tile_w, tile_h, n_ranks, owner, n_frames, rank_stride,
+                        frame_stride, images):
+        per = 3 if rgb8 else 4
+        flat = gathered.reshape(-1, per)
+        if images.dim() == 2:
+            images = images.unsqueeze(0)
+        pic = torch.empty((width * height, per), dtype=torch.uint8)
+        for j in range(n_frames):
+            self._assemble(flat[j * frame_stride:], width, height, tile_w, tile_h, n_ranks, pic, rank_stride, torch.uint8, per,
+                           owner)
+            images[j, :, :per] = pic
+            images[j, :, 3] = 255 if rgb8 else images[j, :, 3]
+
     def set_stream(self, stream):
         pass
 
@@ -68,7 +83,7 @@ class OracleCore:
     def assemble_tiles(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride=0):
         self._assemble(gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride, torch.int32, 2)
 
-    def _assemble(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride, dtype, per):
+    def _assemble(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride, dtype, per, owner=None):
         # `gathered` is a view starting at rank 0's block; ranks are rank_stride records apart
         tiles_x = -(-width // tile_w)
         base = gathered.untyped_storage()
@@ -78,6 +93,10 @@ class OracleCore:
             for x in range(width):
                 tile = (y // tile_h) * tiles_x + x // tile_w
                 r, lt = tile % n_ranks, tile // n_ranks
+                if owner is not None:  # owner[o]: the rank of tile o of every round; its tiles are packed in tile order
+                    q, o = divmod(tile, len(owner))
+                    r = owner[o]
+                    lt = q * owner.count(r) + owner[:o].count(r)
                 src = off + r * rank_stride + lt * tile_w * tile_h + (y % tile_h) * tile_w + x % tile_w
                 image[y * width + x] = flat[src]
 
@@ -122,7 +141,11 @@ def _worker(rank, world, port, tmp):
             ok2 = ok2 and pics[0] is pics[2] and pics[0] is not pics[1]
             open(os.path.join(tmp, "result_rgba"), "w").write(str(int(ok2)))
         # groups of frames: one launch, one gather, one assemble per group; a full group, then a partial one
-        shg = sharding.FrameSharder(OracleCore(ob, scene), W, H, TW, TH, device="cpu", shadow=False, mode="rgba", max_bounces=1)
+        # unequal shares (the gathering rank renders less); the 30 tiles are not a whole number of rounds of 3 or 8
+        weights = [1, 2] if world == 2 else [2, 3, 3]
+        shg = sharding.FrameSharder(OracleCore(ob, scene), W, H, TW, TH, device="cpu", shadow=False, mode="rgba", max_bounces=1,
+                                    weights=weights)
+        assert shg.shard.first == rank and shg.shard.stride == sum(weights) and shg.owner.count(rank) == weights[rank]
         shg.enable_groups(group=3, groups_in_flight=2, rgb8=(world == 3))  # one world size per wire format
         cams = [cam, cam2, ob.camera_to_uniform((150, 120, 250), 3.4, -0.3, 0.0, float(H)), cam2, cam]
         first, second = shg.trace_group(cams[:3]), shg.trace_group(cams[3:])

@@ -32,8 +32,20 @@ def main():
             per_rank = []
             for rank in (range(world - 1, -1, -1) if os.environ.get('RT_REVERSE') else range(world)):
                 sh = sharding.FrameSharder(core, W, H, TILE, TILE_H, rank=rank, world=1, device=dev, shadow=True, mode="rgba", max_bounces=1)
-                sh.shard = rt.RtShard(TILE, TILE_H, rank, world)  # this rank's tiles of a `world`-GPU run, no gather
-                sh.per_rank = sharding.per_rank_pixels(W, H, TILE, TILE_H, world)
+                weights = sharding.gatherer_weights(world) if os.environ.get('RT_WEIGHTED') else None
+                if weights:
+                    owner = sharding.owner_table(weights)
+                    shards = [rt.RtShard(TILE, TILE_H, r, owner=owner) for r in range(world)]
+                    sh.shard = shards[rank]
+                    sh.per_rank = max(rt.shard_pixels(W, H, s) for s in shards)
+                else:
+                    sh.shard = rt.RtShard(TILE, TILE_H, rank, world)  # this rank's tiles of a `world`-GPU run, no gather
+                    sh.per_rank = sharding.per_rank_pixels(W, H, TILE, TILE_H, world)
+                # the gathering rank's extra work: one assemble per group, on the group's stream
+                packed = images = None
+                if rank == 0 and os.environ.get('RT_WITH_ASSEMBLE'):
+                    packed = torch.zeros((world, group, sh.per_rank, 3), dtype=torch.uint8, device=dev)
+                    images = torch.empty((in_flight, group, W * H, 4), dtype=torch.uint8, device=dev)
                 sh.enable_groups(group, in_flight, rgb8=True)
                 cams = [cam] * group
                 slots = sh.gslots
@@ -41,7 +53,11 @@ def main():
                     for k in range(n):
                         slot = slots[k % len(slots)]
                         core.set_stream(slot.stream.cuda_stream)
-                        core.render_frames(cams, W, H, shard=sh.shard, max_bounces=1, shadows=True, out=slot.local, rgb8=True)
+                        core.render_frames(cams, W, H, shard=sh.shard, max_bounces=1, shadows=True, out=slot.local, rgb8=True,
+                                           frame_stride=sh.per_rank)
+                        if packed is not None:
+                            core.assemble_frames(packed, True, W, H, TILE, TILE_H, world, sharding.owner_table(weights) if weights else None, group, group * sh.per_rank,
+                                                 sh.per_rank, images[k % len(slots)])
                     core.sync()
                 run(10)
                 n = max(10, int(os.environ.get('RT_FRAMES', '400')) // group)

@@ -52,6 +52,7 @@ def test_random_scenes(rt, ob):
     import os
     # RT_FUZZ_SEED / RT_FUZZ_TRIALS: longer soak runs with other seeds (the defaults are what the suite runs)
     rng = np.random.default_rng(int(os.environ.get("RT_FUZZ_SEED", "20251111")))
+    srng = np.random.default_rng(int(os.environ.get("RT_FUZZ_SEED", "20251111")) + 1)  # shard choices, a stream of their own
     rays = mism = pixels = pix_mism = 0
     for trial in range(int(os.environ.get("RT_FUZZ_TRIALS", "48"))):
         boxes, tris, ext = random_scene(ob, rng)
@@ -98,6 +99,22 @@ def test_random_scenes(rt, ob):
             pixels += w * h
             pix_mism += badp
             assert badp == 0, f"trial {trial} view {view}: {badp} pixels differ"
+            if view == 1:  # one rank's part of the same frame: plain round-robin, or an owner table with unequal shares
+                tw, th, world = int(srng.choice([8, 16, 20, 32])), int(srng.choice([8, 16, 7])), int(srng.integers(2, 6))
+                rank = int(srng.integers(0, world))
+                owner = None
+                if srng.random() < 0.5:
+                    owner = [int(k) for k in srng.permutation(np.repeat(np.arange(world), srng.integers(1, 4, world)))]
+                shard = rt.RtShard(tw, th, rank, world, owner)
+                oshard = ob.Shard(tw, th, rank, world, owner)
+                p, s = core.trace_primary(cam, w, h, shard=shard)
+                op, os_, _ = ob.trace_primary(scene, oc, w, h, params=params, shard=oshard)
+                bad = int(((p["id"] != op["id"]) | (p["t"].view(np.uint32) != op["t"].view(np.uint32))).sum()
+                          + ((s["id"] != os_["id"]) | (s["t"].view(np.uint32) != os_["t"].view(np.uint32))).sum())
+                assert len(p) == len(op) and bad == 0, f"trial {trial}: shard {tw}x{th} rank {rank}/{world} owner {owner}: {bad} records differ"
+                img = core.render(cam, w, h, max_bounces=bounces, shadows=shadows, shard=shard)
+                oimg, _ = ob.render(scene, oc, w, h, params=params, max_bounces=bounces, shadows=shadows, shard=oshard)
+                assert img.shape == oimg.shape and not (img != oimg).any(), f"trial {trial}: sharded picture differs ({owner})"
         core.close()
     print(f"random scenes: {rays} rays compared, {mism} mismatches; {pixels} shaded pixels compared, {pix_mism} mismatches")
     assert rays > 300000

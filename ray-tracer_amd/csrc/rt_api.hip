@@ -331,7 +331,14 @@ int table_for(rt_ctx* c, std::vector<uint32_t>&& key, const std::vector<uint32_t
             *dev = t->buf.as<uint32_t>();
             return RT_OK;
         }
-    if (c->tables.size() >= 256) return fail(c, RT_ERR_LIMIT, "more than 256 different owner tables in one context");
+    if (c->tables.size() >= 256) {  // a caller that keeps changing its tables: wait for every reader, start over
+        RT_HIP(c, hipDeviceSynchronize());
+        for (rt_table* t : c->tables) {
+            t->buf.release();
+            delete t;
+        }
+        c->tables.clear();
+    }
     rt_table* t = new rt_table;
     c->tables.push_back(t);
     RT_HIP(c, t->buf.reserve(content.size() * sizeof(uint32_t)));

@@ -17,6 +17,7 @@ from ray_tracer_amd import sharding  # noqa: E402
 W, H = 1920, 1080
 TILE = int(os.environ.get("RT_TILE", "32"))
 TILE_H = int(os.environ.get("RT_TILE_H", str(TILE)))
+RGB8 = os.environ.get("RT_WIRE", "rgb") == "rgb"
 
 
 def main():
@@ -44,19 +45,19 @@ def main():
                 # the gathering rank's extra work: one assemble per group, on the group's stream
                 packed = images = None
                 if rank == 0 and os.environ.get('RT_WITH_ASSEMBLE'):
-                    packed = torch.zeros((world, group, sh.per_rank, 3), dtype=torch.uint8, device=dev)
+                    packed = torch.zeros((world, group, sh.per_rank, 3 if RGB8 else 4), dtype=torch.uint8, device=dev)
                     images = torch.empty((in_flight, group, W * H, 4), dtype=torch.uint8, device=dev)
-                sh.enable_groups(group, in_flight, rgb8=True)
+                sh.enable_groups(group, in_flight, rgb8=RGB8)
                 cams = [cam] * group
                 slots = sh.gslots
                 def run(n):
                     for k in range(n):
                         slot = slots[k % len(slots)]
                         core.set_stream(slot.stream.cuda_stream)
-                        core.render_frames(cams, W, H, shard=sh.shard, max_bounces=1, shadows=True, out=slot.local, rgb8=True,
+                        core.render_frames(cams, W, H, shard=sh.shard, max_bounces=1, shadows=True, out=slot.local, rgb8=RGB8,
                                            frame_stride=sh.per_rank)
                         if packed is not None:
-                            core.assemble_frames(packed, True, W, H, TILE, TILE_H, world, sharding.owner_table(weights) if weights else None, group, group * sh.per_rank,
+                            core.assemble_frames(packed, RGB8, W, H, TILE, TILE_H, world, sharding.owner_table(weights) if weights else None, group, group * sh.per_rank,
                                                  sh.per_rank, images[k % len(slots)])
                     core.sync()
                 run(10)

@@ -4,6 +4,7 @@ interleaved rounds, on the headline frame. Needs `make -C ray-tracer_amd/csrc ex
 RT_LIB_PATH=ray-tracer_amd/librt_mi355_exp.so. Every variant is checked against variant-less output first."""
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -48,6 +49,22 @@ if any(v >= 50 for v in variants):
     L.rt_dbg_set_order(core._h, order.ctypes.data_as(C.c_void_p), C.c_size_t(nw))
     print(f"order from {nw} wave times: longest {dur.max() / 100:.1f} us, mean {dur.mean() / 100:.2f} us")
 times = {v: [] for v in variants}
+TWO = os.environ.get("RT_TWO") == "1"  # two frames in flight on two streams, as bench.py runs them
+if TWO:
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    bufs = [(torch.empty_like(p), torch.empty_like(p)) for _ in range(2)]
+
+
+def frames(n):
+    if not TWO:
+        for _ in range(n):
+            core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
+        return
+    for k in range(n):
+        core.set_stream(streams[k % 2].cuda_stream)
+        core.trace_primary(cam, W, H, out_primary=bufs[k % 2][0], out_shadow=bufs[k % 2][1])
+
+
 for v in variants:
     os.environ["RT_VARIANT"] = str(v)
     p.zero_(); s.zero_()
@@ -58,12 +75,17 @@ for v in variants:
 for r in range(rounds):
     for v in variants:
         os.environ["RT_VARIANT"] = str(v)
-        for _ in range(5):
-            core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
-        core.timer_begin()
-        for _ in range(steps):
-            core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
-        times[v].append(core.timer_end() / steps * 1e3)
+        frames(6)
+        core.sync()
+        if TWO:
+            t0 = time.perf_counter()
+            frames(4 * steps)
+            core.sync()
+            times[v].append((time.perf_counter() - t0) / (4 * steps) * 1e6)
+        else:
+            core.timer_begin()
+            frames(steps)
+            times[v].append(core.timer_end() / steps * 1e3)
 for v in variants:
     t = np.array(times[v])
     print(f"variant {v}: median {np.median(t):7.1f} us  min {t.min():7.1f} us")

@@ -316,6 +316,16 @@ def main():
                                "aggregate_achieved": abytes * args.steps / elapsed / 1e9,
                                "algorithmic_bytes_per_launch": abytes, "cells_visited": stats["cells_visited"],
                                "tri_tests": stats["tri_tests"]}
+            vpath = os.path.join(ROOT, "profiles", "valu_counters.json")
+            if os.path.exists(vpath) and WORKLOAD == "car1080":
+                # The bound that actually binds: the frame is read from the caches (traffic above), and its time is the
+                # time the 1 024 SIMDs need to issue the kernel's vector instructions (4 cycles each for a 64-wide wave).
+                v = json.load(open(vpath))
+                issue_us = v["SQ_INSTS_VALU_per_launch"] * 4 / (256 * 4) / 2400.0  # at the 2.4 GHz peak engine clock
+                out["roofline"]["valu_issue"] = {"valu_instructions_per_launch": v["SQ_INSTS_VALU_per_launch"],
+                                                 "issue_us_at_2400MHz": issue_us, "frame_us": ms_per_step * 1e3,
+                                                 "frac": issue_us / (ms_per_step * 1e3),
+                                                 "lanes_active_per_instruction": v["lanes_active_per_valu_instruction"]}
             if WORKLOAD != "car1080":
                 out["roofline"]["note"] = ("algorithmic bytes are those of the reference's full cell lists (counting kernels); "
                                            "the timed kernels leave out exact duplicate triangles, config.trace_refs of config.cell_refs")

@@ -57,7 +57,7 @@ __device__ inline bool near_grid_boundary(const DevScene& s, V3 pos, float thres
 // SINGLE: max_bounces == 1 (direct lighting only): no bounce loop, so the ray origin stays the camera position in
 // scalar registers and nothing is carried from one traversal to the next.
 template <bool WGSL, bool BOXES, bool TEX = false, bool WIDE = false, bool SINGLE = false>
-__global__ __launch_bounds__(256, RT_RENDER_WAVES) void k_render(DevScene s, DevFrames fs, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(256, SINGLE ? 8 : RT_RENDER_WAVES) void k_render(DevScene s, DevFrames fs, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
                                                 unsigned long long* stats) {
     const DevFrame& f = fs.f[blockIdx.y];
     const float show_grid = fs.show_grid[blockIdx.y];

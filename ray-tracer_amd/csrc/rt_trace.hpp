@@ -387,32 +387,37 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     // counters and no range check on the index.
     uint32_t idx = (cx + 1u) + (cy + 1u) * s.px + (cz + 1u) * s.pxy;
     uint2 cell = cell_rec(idx);
-    for (uint32_t i = 0; i < s.max_steps; ++i) {
-        // The step this iteration ends with (:566-587: x if tx < ty and tx < tz, else y if ty < tz, else z)
-        // depends on t_max only; deciding it here keeps it off the candidate loop's exit path and gives the
-        // cell record fetched at the end of the previous iteration time to arrive.
+    // One exit test per step: leaving the grid, the early-out and the step limit all end the loop through the
+    // sentinel count (a stopped ray's next record is overwritten with it). Three separate exits cost a divergent
+    // break each - exec-mask bookkeeping in scalar instructions - on every step of every ray; the one record fetched
+    // past a stop is a neighbour of an inner cell, so it lies inside the bordered array, and nothing reads it.
+    uint32_t left = s.max_steps;
+    if (left == 0) cell.y = CELL_SENTINEL;
+    while (cell.y != CELL_SENTINEL) {
+        // the step this iteration ends with (:566-587: x if tx < ty and tx < tz, else y if ty < tz, else z)
+        // depends on t_max only
         const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
         const bool ay = !ax && t_max.y < t_max.z;
         const bool az = !ax && !ay;
-        const uint32_t idx_next = idx + (ax ? dix : (ay ? diy : diz));
         const float t_exit = fminf(fminf(t_max.x, t_max.y), t_max.z);
-        if (cell.y == CELL_SENTINEL) break;  // the previous step left the grid
         if (STATS) {
             ctr.steps++;
             ctr.cells++;
         }
         const uint32_t n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
         if (n) scan(cell.x, n);
-        // any-hit done, or early-out (:561: the hit lies inside this cell); plain '|' and '&': short-circuit
-        // forms become branches
+        // any-hit done, or early-out (:561: the hit lies inside this cell), or the step limit (:520); plain '|'
+        // and '&': short-circuit forms become branches
         const bool hit = best_id != MISS;
-        if ((ANY & hit) | (hit & (closest < t_exit))) break;
-        idx = idx_next;
+        --left;
+        const bool stop = (ANY & hit) | (hit & (closest < t_exit)) | (left == 0);
+        idx += ax ? dix : (ay ? diy : diz);
         arrival = ax ? mx : (ay ? my : mz);
         t_max.x += ax ? t_delta.x : 0.0f;
         t_max.y += ay ? t_delta.y : 0.0f;
         t_max.z += az ? t_delta.z : 0.0f;
         cell = cell_rec(idx);
+        if (stop) cell.y = CELL_SENTINEL;
     }
     out = HitRec{closest, best_id, best_ref};
     return best_id != MISS;

@@ -414,8 +414,8 @@ bool wide_grid(const DevScene& s) {
     return ((uint64_t)s.n_refs + 1) * 48 > 0xFFFFFFFFull || (uint64_t)s.n_bordered * 8 > 0xFFFFFFFFull;
 }
 
-// Kernel variants: WGSL (constant set), SHADOW / ANY, BOXES (scene has boxes). The counting build is the
-// general one (with the box path); so are the builds for textured alpha and for grids of 4 GiB and more.
+// Kernel variants: WGSL (constant set), SHADOW / ANY, BOXES (scene has boxes), TEX (hits decided by a texture's
+// alpha). The counting build is the general one (with the box path); so is the build for grids of 4 GiB and more.
 template <bool WGSL, bool SHADOW>
 void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* op,
                     uint2* os) {
@@ -454,8 +454,10 @@ void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const D
     } else if (c->tex_mode == 2) {  // hits decided by a texture's alpha: the general kernel with the material path
         if (stats)
             hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
-        else
+        else if (s.nb != 0)
             hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        else
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, false, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
     } else if (stats)
         hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
     else if (s.nb != 0)
@@ -476,8 +478,10 @@ void launch_rays(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const floa
     } else if (c->tex_mode == 2) {
         if (stats)
             hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
-        else
+        else if (s.nb != 0)
             hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+        else
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, false, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
     } else if (stats)
         hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
     else if (s.nb != 0)
@@ -1246,8 +1250,10 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
         if (wgsl) hipLaunchKernelGGL((k_render<true, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
         else hipLaunchKernelGGL((k_render<false, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
     } else if (c->tex_mode != 0) {  // materials name textures: the general kernel with the material path
-        if (wgsl) hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-        else hipLaunchKernelGGL((k_render<false, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        else if (wgsl) hipLaunchKernelGGL((k_render<true, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        else if (has_boxes) hipLaunchKernelGGL((k_render<false, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        else hipLaunchKernelGGL((k_render<false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
     } else if (o.max_bounces == 1) {  // direct lighting only
         if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
         else if (wgsl) hipLaunchKernelGGL((k_render<true, false, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);

@@ -23,7 +23,9 @@ thread_local std::string g_create_error;
 
 // (first, count) per cell, in the bordered layout the trace kernels walk: a one-cell shell of sentinel records
 // around the gx x gy x gz grid.
-__global__ void k_emit_cells(const uint32_t* __restrict__ cell_start, uint32_t gx, uint32_t gy, uint32_t gz,
+// The count is stored already cut to `cap`, the number of entries of a list the traversal looks at
+// (raytracer_unified.wgsl:531 min(count, MAX_OBJECTS_PER_CELL)), so the trace kernels use it as it is.
+__global__ void k_emit_cells(const uint32_t* __restrict__ cell_start, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t cap,
                              uint2* __restrict__ cells) {
     const uint32_t px = gx + 2, py = gy + 2, pz = gz + 2;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,7 +35,7 @@ __global__ void k_emit_cells(const uint32_t* __restrict__ cell_start, uint32_t g
     if (x >= 1 && x <= gx && y >= 1 && y <= gy && z >= 1 && z <= gz) {
         const size_t c = (size_t)(x - 1) + (size_t)(y - 1) * gx + (size_t)(z - 1) * gx * gy;
         const uint32_t a = cell_start[c], b = cell_start[c + 1];
-        rec = make_uint2(a, b - a);
+        rec = make_uint2(a, b - a < cap ? b - a : cap);
     }
     cells[p] = rec;
 }
@@ -259,7 +261,6 @@ DevScene make_scene(const rt_ctx* c) {
     s.px = s.gx + 2;
     s.pxy = s.px * (s.gy + 2);
     s.n_bordered = s.pxy * (s.gz + 2);
-    s.max_per_cell = c->params.max_objects_per_cell;
     s.max_steps = c->params.max_dda_steps;
     s.moving_start = s.nb >= c->params.moving_box_count ? s.nb - c->params.moving_box_count : 0u;
     for (int k = 0; k < 3; ++k) {
@@ -516,7 +517,7 @@ int emit_cells(rt_ctx* c) {
     RT_HIP(c, c->cells.reserve((size_t)bordered * sizeof(uint2)));
     RT_HIP(c, c->refs.reserve(((size_t)c->n_refs_t * 3 + 3) * sizeof(float4)));
     hipLaunchKernelGGL(k_emit_cells, dim3((unsigned)((bordered + 255) / 256)), dim3(256), 0, c->stream,
-                       c->t_cell_start, g[0], g[1], g[2], c->cells.as<uint2>());
+                       c->t_cell_start, g[0], g[1], g[2], c->params.max_objects_per_cell, c->cells.as<uint2>());
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }

@@ -5,7 +5,7 @@
 // (src/raytracer_unified.wgsl:430-588 trace_ray, :625-653 ray generation).
 //
 // Data layout in HBM (built by rt_build.hip / the gather kernels in rt_api.hip):
-//   cells[c]      uint2 (first ref, ref count) per fine grid cell, with a one-cell border on every side whose
+//   cells[c]      uint2 (first ref, ref count cut to the per-cell cap) per fine grid cell, with a one-cell border on every side whose
 //                 count is CELL_SENTINEL: c = (x+1) + (y+1)*px + (z+1)*px*py, px = gx+2, py = gy+2
 //   refs[3*r..]   one 48-byte record per (cell, object) reference, stored in cell order so a
 //                 cell's candidates are contiguous:  (v0.xyz, id bits) (e1.xyz, 0) (e2.xyz, 0)
@@ -41,7 +41,7 @@ struct DevScene {
     uint32_t gx, gy, gz;
     uint32_t px, pxy;  // strides of the bordered cell array: gx + 2 and (gx + 2) * (gy + 2)
     uint32_t n_bordered;  // its length: (gx + 2) * (gy + 2) * (gz + 2)
-    uint32_t max_per_cell, max_steps, moving_start;
+    uint32_t max_steps, moving_start;
     float bmin[3], bmax[3];
     float cell_size;
     float inv_cell_size;  // 1 / max(cell_size, 1e-8), evaluated once on the host
@@ -355,7 +355,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
                 const uint32_t x = fi % s.gx, y = (fi / s.gx) % s.gy, z = fi / (s.gx * s.gy);
                 const uint2 cell = cell_rec((x + 1u) + (y + 1u) * s.px + (z + 1u) * s.pxy);
                 first = cell.x;
-                n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
+                n = cell.y;  // an inner cell; counts are stored cut to the cap
             }
             if (n) scan(first, n);
             const bool hit = best_id != MISS;
@@ -404,7 +404,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             ctr.steps++;
             ctr.cells++;
         }
-        const uint32_t n = cell.y < s.max_per_cell ? cell.y : s.max_per_cell;
+        const uint32_t n = cell.y;  // stored cut to the cap of raytracer_unified.wgsl:531
         if (n) scan(cell.x, n);
         // any-hit done, or early-out (:561: the hit lies inside this cell), or the step limit (:520); plain '|'
         // and '&': short-circuit forms become branches

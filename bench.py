@@ -9,7 +9,8 @@ hit, all inside one kernel launch, with scene, grid and output buffers resident 
 with a two-image swap chain, consecutive frames go to two streams with their own output buffers (two frames in
 flight): a frame's last waves - a few pixel blocks over the model's densest cells, one long dependent chain
 each - then overlap the next frame's bulk instead of leaving the GPU idle. At N > 1
-the SAME frame is cut into 32x32 tiles dealt round-robin to the ranks, each rank shades its tiles (same
+the SAME frame is cut into 32x32 tiles dealt to the ranks (rank 0, which also gathers and assembles, gets 5 of every 61
+at N = 8 where the others get 8), each rank shades its tiles (same
 primary + shadow rays) and the RGBA8 framebuffer is gathered on rank 0 by RCCL (total work fixed: strong
 scaling; 3 bytes per pixel cross the links - the picture without its constant alpha byte - instead of 16 for hit
 records). A rank's share of one 1080p frame is

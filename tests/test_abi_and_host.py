@@ -78,6 +78,9 @@ def test_shard_pixels_matches_oracle(rt, ob):
     # unequal shares through an owner table; together the ranks cover every tile once
     from ray_tracer_amd import sharding
     assert sharding.owner_table([3, 4, 4]) == [0, 1, 2, 0, 1, 2, 0, 1, 2, 1, 2]
+    # what bench.py deals at N = 2, 4, 8: the gathering rank three parts in 64 short of an equal share
+    assert sharding.gatherer_weights(1) is None and sharding.gatherer_weights(2) == [29, 32]
+    assert sharding.gatherer_weights(4) == [13, 16, 16, 16] and sharding.gatherer_weights(8) == [5] + [8] * 7
     for (w, h, tw, th, weights) in ((1920, 1080, 32, 32, (5, 8, 8, 8, 8, 8, 8, 8)), (150, 85, 32, 16, (2, 3, 3)), (70, 45, 16, 8, (1, 5))):
         owner = sharding.owner_table(weights)
         assert len(owner) == sum(weights) and all(owner.count(r) == k for r, k in enumerate(weights))

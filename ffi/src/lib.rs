@@ -37,6 +37,9 @@ extern "C" {
     pub fn rt_update_vertices(ctx: *mut RtCtx, xyz9: *const f32, first: u32, count: u32) -> c_int;
     pub fn rt_trace_primary(ctx: *mut RtCtx, camera: *const c_void, width: u32, height: u32, shard: *const RtShard,
                             out_primary: *mut RtHit, out_shadow: *mut RtHit) -> c_int;
+    /// `rt_trace_primary` without any device allocation (device outputs only; see include/rt_mi355.h).
+    pub fn rt_trace_primary_noalloc(ctx: *mut RtCtx, camera: *const c_void, width: u32, height: u32, shard: *const RtShard,
+                                    out_primary: *mut RtHit, out_shadow: *mut RtHit) -> c_int;
     pub fn rt_trace_rays(ctx: *mut RtCtx, camera: *const c_void, origins: *const f32, dirs: *const f32, n: u32,
                          out: *mut RtHit, any_hit: c_int) -> c_int;
     pub fn rt_set_stream(ctx: *mut RtCtx, hip_stream: *mut c_void) -> c_int;

@@ -190,6 +190,24 @@ int rt_update_vertices(rt_ctx* ctx, const float* xyz9, uint32_t first, uint32_t 
 int rt_trace_primary(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
                      const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow);
 
+/* rt_trace_primary for callers that cannot allocate device memory while they run: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc. No counterpart in the reference. Same arguments, same
+ * results; it calls no hipMalloc / hipFree and no allocating routine. The one buffer a trace needs beyond its inputs
+ * and outputs - the per-frame box records (interpolated bounds and LOD-cull outcomes, 64 bytes per box) - lives in
+ * a static device array of RT_NOALLOC_MAX_BOXES records (512 KiB) that every GPU the library runs on holds until
+ * the process ends. Restrictions, each reported as an error, nothing is silently downgraded:
+ *   - out_primary / out_shadow must be device memory (a host output would need a staging buffer)   RT_ERR_INVALID
+ *   - scenes with more than RT_NOALLOC_MAX_BOXES boxes                                               RT_ERR_LIMIT
+ *   - params.collect_stats must be 0                                                                 RT_ERR_STATE
+ *   - a shard with an owner table only if an allocating call has used that table before             RT_ERR_STATE
+ * Every call on a GPU shares that GPU's array, whichever context it comes from: calls on one context are ordered
+ * as rt_set_stream describes, calls from DIFFERENT contexts that overlap on one GPU race when their scenes have
+ * boxes. The array keeps the last call's records; every call rewrites all records it reads, so nothing needs
+ * clearing between calls. */
+#define RT_NOALLOC_MAX_BOXES 8192u
+int rt_trace_primary_noalloc(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
+                             const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow);
+
 /* Ray-list mode (the reference's CPU benches trace explicit ray lists:
  * examples/massive_benchmark.rs:90-98). origins/dirs: n*3 floats each (host or device).
  * camera supplies position/time/lod for the box LOD cull and may be NULL when the

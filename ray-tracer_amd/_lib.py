@@ -31,6 +31,7 @@ assert MATERIAL_DTYPE.itemsize == 64
 RT_MISS = 0xFFFFFFFF
 RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_STATE, RT_ERR_LIMIT = 0, -1, -2, -3, -4, -5
 RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES = 0, 1
+RT_NOALLOC_MAX_BOXES = 8192
 
 
 class CameraUniform(C.Structure):
@@ -125,6 +126,7 @@ PROTOTYPES = {
     "rt_read_grid_csr": (_I, [_VP, _VP, _VP]),
     "rt_update_vertices": (_I, [_VP, _VP, _U32, _U32]),
     "rt_trace_primary": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), _VP, _VP]),
+    "rt_trace_primary_noalloc": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), _VP, _VP]),
     "rt_trace_rays": (_I, [_VP, C.POINTER(CameraUniform), _VP, _VP, _U32, _VP, _I]),
     "rt_assemble_tiles": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
     "rt_build_bvh": (_I, [_VP]),

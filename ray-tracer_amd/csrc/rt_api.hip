@@ -2,6 +2,7 @@
 // Host code here only moves bytes, evaluates the per-frame constants and launches kernels;
 // everything a ray does happens in rt_trace.hpp, grid binning in rt_build.hip.
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "rt_internal.hpp"
@@ -18,6 +19,28 @@ using namespace rt;
 namespace {
 
 thread_local std::string g_create_error;
+
+// ---------------------------------------------------------------- scratch of the entry point that allocates nothing
+// rt_trace_primary_noalloc keeps the one buffer a trace needs beyond its inputs and outputs - the per-frame box
+// records k_box_frame writes and the trace kernels read - in this array instead of a hipMalloc'ed one. Every GPU the
+// library runs on holds its own copy (512 KiB) at its own address until the process ends. In host code the array's
+// name is only a handle for hipGetSymbolAddress: rt_create asks once per device, with that device current, and
+// everything below passes the address it got (g_scratch_ptr[device]) - never the name - to kernels.
+constexpr uint32_t NOALLOC_MAX_BOXES = 8192;
+static __device__ __align__(256) float4 scratch[4 * NOALLOC_MAX_BOXES];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+float4* g_scratch_ptr[NOALLOC_MAX_DEVICES];  // written under g_scratch_lock, read after rt_create returned
+std::mutex g_scratch_lock;
+
+hipError_t scratch_for_device(int device) {  // the device must be current
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return hipSuccess;  // rt_trace_primary_noalloc reports it
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e == hipSuccess) g_scratch_ptr[device] = static_cast<float4*>(p);
+    return e;
+}
 
 // ---------------------------------------------------------------- small kernels
 
@@ -326,12 +349,15 @@ int update_box_frame(rt_ctx* c, const CameraUniform* cam) { return update_box_fr
 constexpr uint32_t MAX_OWNER_TABLE = 4096;
 
 // Device copy of `content`, uploaded the first time `key` is seen.
-int table_for(rt_ctx* c, std::vector<uint32_t>&& key, const std::vector<uint32_t>& content, const uint32_t** dev) {
+int table_for(rt_ctx* c, std::vector<uint32_t>&& key, const std::vector<uint32_t>& content, const uint32_t** dev,
+              bool may_upload = true) {
     for (rt_table* t : c->tables)
         if (t->key == key) {
             *dev = t->buf.as<uint32_t>();
             return RT_OK;
         }
+    if (!may_upload)
+        return fail(c, RT_ERR_STATE, "this owner table is not on the device yet: make one allocating call with this shard first");
     if (c->tables.size() >= 256) {  // a caller that keeps changing its tables: wait for every reader, start over
         RT_HIP(c, hipDeviceSynchronize());
         for (rt_table* t : c->tables) {
@@ -349,7 +375,7 @@ int table_for(rt_ctx* c, std::vector<uint32_t>&& key, const std::vector<uint32_t
     return RT_OK;
 }
 
-int make_shard(rt_ctx* c, uint32_t w, uint32_t h, const rt_shard* sh, ShardMap* out, const char* who) {
+int make_shard(rt_ctx* c, uint32_t w, uint32_t h, const rt_shard* sh, ShardMap* out, const char* who, bool may_upload = true) {
     ShardMap m;
     memset(&m, 0, sizeof(m));
     if (sh && (!sh->tile_w || !sh->tile_h || !sh->stride))
@@ -380,7 +406,7 @@ int make_shard(rt_ctx* c, uint32_t w, uint32_t h, const rt_shard* sh, ShardMap* 
         if (m.count == 0) {
             m.count = 1;  // this rank owns nothing: an empty call
             m.n_local = 0;
-        } else if (int r = table_for(c, std::move(key), mine, &m.offsets)) {
+        } else if (int r = table_for(c, std::move(key), mine, &m.offsets, may_upload)) {
             return r;
         }
     }
@@ -574,6 +600,10 @@ extern "C" int rt_create(rt_ctx** out, int device_id, const rt_params* params) {
     }
     if ((e = hipSetDevice(device_id)) != hipSuccess) {
         g_create_error = std::string("rt_create: hipSetDevice: ") + hipGetErrorString(e);
+        return RT_ERR_NO_DEVICE;
+    }
+    if ((e = scratch_for_device(device_id)) != hipSuccess) {
+        g_create_error = std::string("rt_create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
         return RT_ERR_NO_DEVICE;
     }
     rt_ctx* c = new rt_ctx();
@@ -862,21 +892,35 @@ extern "C" int rt_update_vertices(rt_ctx* c, const float* xyz9, uint32_t first, 
 
 // ================================================================== tracing
 
-extern "C" int rt_trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height,
-                                const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow) {
+// NOALLOC: the form that allocates nothing (rt_trace_primary_noalloc): device outputs only, no counters, owner tables
+// only if already resident, per-frame box records in the static scratch array of this device.
+template <bool NOALLOC>
+static int trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height, const rt_shard* shard,
+                         rt_hit* out_primary, rt_hit* out_shadow, const char* who) {
     if (int r = use(c)) return r;
-    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_trace_primary: no grid (call rt_build_grid or rt_set_grid_*)");
-    if (!cam || !out_primary) return fail(c, RT_ERR_INVALID, "rt_trace_primary: NULL camera or output");
-    if (!width || !height) return fail(c, RT_ERR_INVALID, "rt_trace_primary: empty frame");
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "%s: no grid (call rt_build_grid or rt_set_grid_*)", who);
+    if (!cam || !out_primary) return fail(c, RT_ERR_INVALID, "%s: NULL camera or output", who);
+    if (!width || !height) return fail(c, RT_ERR_INVALID, "%s: empty frame", who);
+    float4* static_boxes = nullptr;
+    if (NOALLOC) {
+        if (c->params.collect_stats) return fail(c, RT_ERR_STATE, "%s: counters are not available here (collect_stats is on)", who);
+        if (c->grid_nb > NOALLOC_MAX_BOXES)
+            return fail(c, RT_ERR_LIMIT, "%s: the scene has %u boxes, the static scratch holds the per-frame records of %u", who,
+                        c->grid_nb, NOALLOC_MAX_BOXES);
+        if (c->device >= NOALLOC_MAX_DEVICES || !(static_boxes = g_scratch_ptr[c->device]))
+            return fail(c, RT_ERR_LIMIT, "%s: no static scratch on device %d (devices 0 to %d have one)", who, c->device,
+                        NOALLOC_MAX_DEVICES - 1);
+    }
     ShardMap m;
-    if (int r = make_shard(c, width, height, shard, &m, "rt_trace_primary")) return r;
+    if (int r = make_shard(c, width, height, shard, &m, who, !NOALLOC)) return r;
     const size_t n_out = (size_t)m.n_local * m.tile_w * m.tile_h;
     if (n_out == 0) return RT_OK;
     const uint64_t blocks = (uint64_t)m.n_local * ((m.sub_x + 1) / 2) * ((m.sub_y + 1) / 2);  // 16x16 pixels each
-    if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "rt_trace_primary: frame too large");
+    if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "%s: frame too large", who);
 
     const bool host_p = !is_device_ptr(out_primary);
     const bool host_s = out_shadow && !is_device_ptr(out_shadow);
+    if (NOALLOC && (host_p || host_s)) return fail(c, RT_ERR_INVALID, "%s: outputs must be device memory", who);
     uint2* op = reinterpret_cast<uint2*>(out_primary);
     uint2* os = reinterpret_cast<uint2*>(out_shadow);
     if (host_p) {
@@ -887,12 +931,23 @@ extern "C" int rt_trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t wi
         RT_HIP(c, c->out_s.reserve(n_out * sizeof(uint2)));
         os = c->out_s.as<uint2>();
     }
-    if (int r = update_box_frame(c, cam)) return r;
+    if (NOALLOC) {
+        if (c->grid_nb) {  // every record of boxes 0 .. nb-1 is rewritten: nothing in the array has to start at zero
+            const float t_lerp = (sinf(cam->time * 2.0f) + 1.0f) * 0.5f;  // raytracer_unified.wgsl:201,449
+            hipLaunchKernelGGL(k_box_frame, dim3((c->nb + 255) / 256), dim3(256), 0, c->stream, c->boxes.as<BoxData>(), c->nb,
+                               t_lerp, ld3(cam->position), cam->lod_factor, cam->min_pixel_size, c->params.lod_cull, static_boxes);
+            RT_HIP(c, hipGetLastError());
+            c->scratch_busy = true;  // a later call on another stream of this context is ordered behind this one
+        }
+    } else if (int r = update_box_frame(c, cam)) {
+        return r;
+    }
     const bool stats = c->params.collect_stats != 0;
     if (stats)
         if (int r = zero_stats(c)) return r;
 
-    const DevScene s = make_scene(c);
+    DevScene s = make_scene(c);
+    if (NOALLOC) s.box_frame = static_boxes;
     const DevFrame f = make_frame(c, cam, width, height);
     const dim3 grid((uint32_t)blocks);
     const bool wgsl = c->params.wgsl_compat != 0;
@@ -916,6 +971,17 @@ extern "C" int rt_trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t wi
         RT_HIP(c, hipStreamSynchronize(c->stream));
     }
     return RT_OK;
+}
+
+extern "C" int rt_trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height,
+                                const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow) {
+    return trace_primary<false>(c, cam, width, height, shard, out_primary, out_shadow, "rt_trace_primary");
+}
+
+// Calls no hipMalloc / hipFree and no routine that allocates: see the scratch array at the top of this file.
+extern "C" int rt_trace_primary_noalloc(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height,
+                                        const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow) {
+    return trace_primary<true>(c, cam, width, height, shard, out_primary, out_shadow, "rt_trace_primary_noalloc");
 }
 
 extern "C" int rt_trace_rays(rt_ctx* c, const CameraUniform* cam, const float* origins, const float* dirs, uint32_t n,

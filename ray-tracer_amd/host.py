@@ -260,6 +260,13 @@ class TraceCore:
                                           _ptr(out_shadow) if shadow else None))
         return out_primary, (out_shadow if shadow else None)
 
+    def trace_primary_noalloc(self, cam, width, height, out_primary, out_shadow=None, shard=None):
+        """rt_trace_primary_noalloc: the same trace without any device allocation; outputs must be device memory
+        (torch CUDA tensors or raw device pointers)."""
+        self._ck(self._L.rt_trace_primary_noalloc(self._h, _ref(cam, CameraUniform), width, height, _ref(shard, RtShard),
+                                                  _ptr(out_primary), _ptr(out_shadow)))
+        return out_primary, out_shadow
+
     def trace_rays(self, origins, dirs, cam=None, any_hit=False, out=None, n=None):
         if isinstance(origins, np.ndarray):
             origins = np.ascontiguousarray(origins, np.float32)

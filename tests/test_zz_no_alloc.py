@@ -1,0 +1,137 @@
+"""rt_trace_primary_noalloc against rt_trace_primary, through the C ABI, bit for bit.
+
+The entry point keeps its per-frame box records in a static device array instead of a hipMalloc'ed buffer, so the
+scenes here have boxes (moving ones included: their records change with the camera's time). Two calls in a row, the
+second on a smaller scene and a smaller frame, because the array keeps whatever the last call left in it.
+Named so that pytest collects it last: it shares one GPU-wide array with nothing else, but a failure here must not
+hide the other tests under `pytest -x`."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(ob, n, seed, moving_last):
+    rng = np.random.default_rng(seed)
+    boxes = np.zeros(n, ob.BOX_DTYPE)
+    for i in range(n):
+        c = rng.uniform(-45.0, 45.0, 3).astype(np.float32)
+        h = rng.uniform(0.5, 6.0, 3).astype(np.float32)
+        if i >= n - moving_last:  # BoxData::create_moving_box, src/types.rs:123-151
+            c1 = (c + rng.uniform(-10, 10, 3)).astype(np.float32)
+            lo = np.minimum(c - h, c1 - h) - np.float32(0.5)
+            hi = np.maximum(c + h, c1 + h) + np.float32(0.5)
+            boxes[i] = ob.make_box(lo, hi, center0=c, center1=c1, half=h)
+        else:
+            boxes[i] = ob.make_box(c - h, c + h)
+    return boxes
+
+
+def _both(core, torch, cam, w, h, shard=None, n=None):
+    """(existing entry point, new entry point) outputs as numpy uint32 arrays; all four buffers on the device."""
+    n = w * h if n is None else n
+    bufs = [torch.full((n, 2), 0x5A5A5A5A, dtype=torch.int32, device="cuda") for _ in range(4)]
+    core.trace_primary(cam, w, h, shard=shard, shadow=True, out_primary=bufs[0], out_shadow=bufs[1])
+    free0 = torch.cuda.mem_get_info()[0]
+    core.trace_primary_noalloc(cam, w, h, bufs[2], bufs[3], shard=shard)
+    core.sync()
+    assert torch.cuda.mem_get_info()[0] == free0, "free device memory changed across rt_trace_primary_noalloc"
+    return [b.cpu().numpy().view(np.uint32) for b in bufs]
+
+
+def test_noalloc_trace_equals_the_allocating_one(rt, ob):
+    import torch
+    core = rt.TraceCore(0)
+    try:
+        # first call: 150 boxes (3 moving) and 3000 triangles, 320 x 180
+        boxes, tris = _boxes(ob, 150, 21, 3), ob.generate_test_triangles(3000)
+        core.set_scene(boxes, tris)
+        core.build_grid(cell_size=8.0)
+        cam = rt.Camera((10, 30, 140), math.pi, -0.2).to_uniform(0.9, 180.0)
+        p0, s0, p1, s1 = _both(core, torch, cam, 320, 180)
+        assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
+        ids = p0[:, 0]
+        assert ((ids < 150).sum() > 200) and ((ids >= 150) & (ids != rt.RT_MISS)).sum() > 200  # boxes and triangles hit
+        assert (s0[:, 0] != rt.RT_MISS).sum() > 50
+        # and against the oracle, so that "equal" cannot mean "equally wrong"
+        scene = ob.Scene(boxes, tris, cell_size=8.0)
+        ocam = ob.CameraUniform()
+        C.memmove(C.byref(ocam), C.byref(cam), C.sizeof(ocam))
+        op, osd, _ = ob.trace_primary(scene, ocam, 320, 180)
+        assert np.array_equal(p1[:, 0], op["id"]) and np.array_equal(p1[:, 1], op["t"].view(np.uint32))
+        assert np.array_equal(s1[:, 0], osd["id"]) and np.array_equal(s1[:, 1], osd["t"].view(np.uint32))
+
+        # second call, smaller input: 40 boxes (all three moving ones at another time), fewer triangles, 96 x 54;
+        # records 40 .. 149 of the array still hold the first scene's boxes and must not matter
+        boxes2, tris2 = _boxes(ob, 40, 22, 3), ob.generate_test_triangles(1200)
+        core.set_scene(boxes2, tris2)
+        core.build_grid(cell_size=8.0)
+        cam2 = rt.Camera((-20, 25, 130), math.pi + 0.15, -0.15).to_uniform(2.3, 54.0)
+        q0, t0, q1, t1 = _both(core, torch, cam2, 96, 54)
+        assert np.array_equal(q0, q1) and np.array_equal(t0, t1)
+        assert (q0[:, 0] < 40).sum() > 20
+        scene2 = ob.Scene(boxes2, tris2, cell_size=8.0)
+        C.memmove(C.byref(ocam), C.byref(cam2), C.sizeof(ocam))
+        op, osd, _ = ob.trace_primary(scene2, ocam, 96, 54)
+        assert np.array_equal(q1[:, 0], op["id"]) and np.array_equal(q1[:, 1], op["t"].view(np.uint32))
+        assert np.array_equal(t1[:, 0], osd["id"]) and np.array_equal(t1[:, 1], osd["t"].view(np.uint32))
+
+        # a shard without an owner table works; one with a table only after an allocating call has uploaded it
+        sh = rt.RtShard(32, 32, 1, 3)
+        n = rt.shard_pixels(96, 54, sh)
+        a0, b0, a1, b1 = _both(core, torch, cam2, 96, 54, shard=sh, n=n)
+        assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
+        own = rt.RtShard(32, 32, 0, owner=[0, 1, 1])
+        n = rt.shard_pixels(96, 54, own)
+        out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+        with pytest.raises(rt.RtError) as e:
+            core.trace_primary_noalloc(cam2, 96, 54, out, None, shard=own)
+        assert e.value.code == rt.RT_ERR_STATE
+        a0, b0, a1, b1 = _both(core, torch, cam2, 96, 54, shard=own, n=n)  # the allocating call goes first in _both
+        assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
+    finally:
+        core.close()
+
+
+def test_noalloc_limits_are_errors(rt, ob):
+    import torch
+    core = rt.TraceCore(0)
+    try:
+        tris = ob.generate_test_triangles(500)
+        core.set_scene(None, tris)
+        core.build_grid(cell_size=8.0)
+        cam = rt.Camera((10, 30, 140), math.pi, -0.2).to_uniform(0.0, 54.0)
+        dev = torch.empty((96 * 54, 2), dtype=torch.int32, device="cuda")
+        host = np.empty(96 * 54, rt.HIT_DTYPE)
+        with pytest.raises(rt.RtError) as e:  # a host output needs a staging buffer
+            core.trace_primary_noalloc(cam, 96, 54, host)
+        assert e.value.code == rt.RT_ERR_INVALID
+        core.set_collect_stats(True)
+        with pytest.raises(rt.RtError) as e:
+            core.trace_primary_noalloc(cam, 96, 54, dev)
+        assert e.value.code == rt.RT_ERR_STATE
+        core.set_collect_stats(False)
+        core.trace_primary_noalloc(cam, 96, 54, dev)  # no shadow records asked for
+        want, _ = core.trace_primary(cam, 96, 54, shadow=False)
+        core.sync()
+        assert np.array_equal(dev.cpu().numpy().view(np.uint32).reshape(-1), want.view(np.uint32))
+        # more boxes than the static array holds records for
+        from ray_tracer_amd import _lib
+        many = np.zeros(_lib.RT_NOALLOC_MAX_BOXES + 1, ob.BOX_DTYPE)
+        many["min"], many["max"] = (0, 0, 0), (1, 1, 1)
+        many["center0"] = many["center1"] = (0.5, 0.5, 0.5)
+        many["half_size"] = (0.5, 0.5, 0.5)
+        many["min"][:, 0] += np.arange(len(many), dtype=np.float32) * 2
+        many["max"][:, 0] += np.arange(len(many), dtype=np.float32) * 2
+        many["center0"][:, 0] += np.arange(len(many), dtype=np.float32) * 2
+        many["center1"][:, 0] += np.arange(len(many), dtype=np.float32) * 2
+        core.set_scene(many, None)
+        core.build_grid(cell_size=64.0)
+        with pytest.raises(rt.RtError) as e:
+            core.trace_primary_noalloc(cam, 96, 54, dev)
+        assert e.value.code == rt.RT_ERR_LIMIT and "8192" in str(e.value)
+    finally:
+        core.close()

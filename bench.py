@@ -174,8 +174,8 @@ def main():
         xyz9 = np.load(os.path.join(ROOT, "tests", "golden", "car_tris.npy"))
         tris = rt.triangles_from_xyz9(xyz9) if rank == 0 else None
         pose = rt.Camera.for_scene("gltf")
-        data = ("synthetic camera path on the reference's bundled static model (models/no_animation, 3132 triangles, "
-                "flattened to a fixture)")
+        data = ("one frame, repeated every step (same camera, caches warm), of the reference's bundled static model "
+                "(models/no_animation, 3132 triangles, flattened to a fixture); no file or dataset is read in the timed region")
         workload = ("configs[1]: static model, 1920x1080 primary rays through the DDA uniform grid "
                     "+ one shadow ray per primary hit, SCENE=gltf start camera")
     if multi:  # scene replicated by one RCCL broadcast, grid binned locally on every GPU

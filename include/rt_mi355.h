@@ -353,7 +353,10 @@ int rt_assemble_frames(rt_ctx* ctx, const uint8_t* gathered, uint32_t pixel_form
                        uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, const uint32_t* owner, uint32_t round,
                        uint32_t n_frames, size_t rank_stride, size_t frame_stride, uint8_t* images);
 
-/* Counters of the most recent trace call made with params.collect_stats = 1. */
+/* Counters of the most recent call made with params.collect_stats = 1. rt_trace_primary and rt_trace_rays fill
+ * every field (their counting kernels walk the reference's full lists). rt_render / rt_render_frames fill rays,
+ * primary_hits, shadow_rays and shadow_hits only: cells_visited, tri_tests and box_tests read 0 after them (the
+ * picture kernels have no counting instantiation). */
 int rt_get_stats(rt_ctx* ctx, rt_stats* stats);
 int rt_set_collect_stats(rt_ctx* ctx, int enabled);
 

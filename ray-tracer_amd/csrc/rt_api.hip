@@ -1070,7 +1070,9 @@ static int assemble_tiles(rt_ctx* c, const void* gathered, uint32_t width, uint3
     if (n_frames == 0) return RT_OK;
     if (n_frames > 65535u) return fail(c, RT_ERR_LIMIT, "%s: more than 65535 frames", who);
     if (n_frames > 1 && !rank_stride) return fail(c, RT_ERR_INVALID, "%s: rank_stride is required", who);
-    if (per_rank < min_stride || (n_frames > 1 && (frame_stride < min_stride || per_rank < (size_t)n_frames * min_stride)))
+    // the last frame of a rank's block must end inside the block: the kernels do no bounds checking
+    if (per_rank < min_stride ||
+        (n_frames > 1 && (frame_stride < min_stride || (size_t)(n_frames - 1) * frame_stride + min_stride > per_rank)))
         return fail(c, RT_ERR_INVALID, "%s: frame_stride / rank_stride smaller than the blocks they hold", who);
     constexpr uint32_t PER = 16 / sizeof(PIXEL);
     const bool by_vectors = tile_w % PER == 0 && width % PER == 0 && per_rank % PER == 0 &&

@@ -90,6 +90,13 @@ def broadcast_scene(boxes, tris, device, src=0):
     return b, t
 
 
+def _order_after_fill(stream, device):
+    """The buffers of a slot are filled (zeros / "miss") on torch's current stream; the slot's own stream, which is
+    non-blocking and carries the first frame's kernels, must not start before those fills have finished."""
+    if stream is not None:
+        stream.wait_stream(torch.cuda.current_stream(device))
+
+
 class _Slot:
     """Buffers and stream of one frame in flight."""
 
@@ -111,6 +118,7 @@ class _Slot:
                 self.image = torch.empty((s.height * s.width, 4), dtype=torch.uint8, device=device)
             else:
                 self.image = torch.empty((s.blocks, s.height * s.width, 2), dtype=torch.int32, device=device)
+        _order_after_fill(self.stream, device)
 
 
 class _GroupSlot:
@@ -125,6 +133,7 @@ class _GroupSlot:
         if s.rank == 0:
             self.packed = torch.empty((s.world, s.group, s.per_rank, s.wire_bytes), dtype=torch.uint8, device=device)
             self.images = torch.empty((s.group, s.height * s.width, 4), dtype=torch.uint8, device=device)
+        _order_after_fill(self.stream, device)
 
 
 class FrameSharder:

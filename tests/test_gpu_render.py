@@ -408,3 +408,7 @@ def test_unequal_shares_render_and_assemble(core, ob, rt, car_xyz9):
         core.assemble_frames(packed, True, w, h, tw, th, 2, owner, len(cams), len(cams) * per, per, images)
     with pytest.raises(rt.RtError):
         core.render_frames(cams, w, h, shard=shards[1], out=packed[1], rgb8=True, frame_stride=per // 4)
+    # frames a stride apart that is wider than a frame: the last frame must still end inside the rank's block
+    with pytest.raises(rt.RtError) as e:
+        core.assemble_frames(packed, True, w, h, tw, th, len(counts), owner, len(cams), len(cams) * per, per + per // 2, images)
+    assert e.value.code == rt.RT_ERR_INVALID

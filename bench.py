@@ -19,8 +19,20 @@ groups of GROUP consecutive frames: one launch renders the rank's tiles of the w
 one launch assembles them (a renderer running a camera path ahead of display); every frame is still traced,
 gathered and assembled in full inside the timed region. Prints one JSON line on rank 0.
 
-The frame's work (cells visited, candidates tested, rays) is counted by the kernel's own counters in an
-untimed launch. The CPU oracle is used for one thing only, outside the timed region: the `cpu_baseline`
+The frame's work is counted by the kernel's own counters in two untimed launches: what the REFERENCE algorithm
+does (cells visited, candidates tested: the algorithmic byte count) and what the shipped kernel fetches (cell and
+reference records it asks the memory system for, after re-test skipping, duplicate removal and LDS staging).
+
+Two roofline objects on the line (N = 1):
+  roofline            the headline frame. Its scene (2.5 MB) lives in the caches, so the bound is not HBM: `bound` is
+                      "valu_issue" (vector instructions issued per second against the 1 024 SIMDs' issue rate, from the
+                      committed hardware-counter pass), and the measured HBM traffic is given beside it as a fraction
+                      of the HBM peak. Algorithmic bytes per second are reported, never as a fraction of anything.
+  roofline_streaming  a second leg whose scene does NOT fit the caches (RT_BENCH_STREAM_TRIANGLES distinct triangles,
+                      default 10 M: 1.6 GB of reference records, 3840x2160, camera inside the volume so every pixel's
+                      ray traverses it): `bound` "hbm", `achieved` = algorithmic bytes per launch / average launch
+                      duration (HIP events on the launch stream), `traffic` = HBM bytes per launch from the committed
+                      counter pass of the same command. The CPU oracle is used for one thing only, outside the timed region: the `cpu_baseline`
 leg times the reference's CPU trace path (BVH build + both-children traversal, restated in oracle/) on
 the host cores.
 """
@@ -60,6 +72,101 @@ def algorithmic_bytes(stats):
     """Per launch: 8 B per visited cell record, 4 B index + 36 B vertices per triangle candidate
     (24 B per box candidate), 8 B hit record per ray."""
     return 8 * stats["cells_visited"] + 40 * stats["tri_tests"] + 28 * stats["box_tests"] + 8 * stats["rays"]
+
+
+def moved_bytes(stats, pixels, shadow=True):
+    """Per launch: what the shipped kernel requests from the memory system - 8 B per cell record fetched, 48 B per
+    reference record fetched (by a lane for itself, look-ahead included, or once per wave into LDS), 8 B per hit
+    record written (primary and shadow record of every pixel)."""
+    return (8 * stats["cell_records_fetched"] + 48 * (stats["ref_records_fetched"] + stats["ref_records_staged"])
+            + 8 * pixels * (2 if shadow else 1))
+
+
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2  # 1 024 SIMDs, one 64-wide vector instruction per 2 cycles each, 2.4 GHz
+
+
+def profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+
+def count_frame(core, cam, width, height, outs):
+    """(reference-algorithm counters, shipped-kernel fetch counters) of one frame, untimed."""
+    core.set_collect_stats(1)
+    core.trace_primary(cam, width, height, shadow=True, out_primary=outs[0], out_shadow=outs[1])
+    ref = core.stats()
+    core.set_collect_stats(2)
+    core.trace_primary(cam, width, height, shadow=True, out_primary=outs[0], out_shadow=outs[1])
+    mov = core.stats()
+    core.set_collect_stats(0)
+    return ref, mov
+
+
+def streaming_leg(rt, dev, steps, warmup):
+    """A frame whose scene does not fit the caches: n distinct small random triangles (seeded) in a 100-unit cube,
+    cells of one mean spacing, 3840x2160 primary + shadow, camera inside the cube's front face region so
+    that every primary ray enters the grid. One stream, launches back to back: the HIP-event time divided by the
+    launches is one launch's duration."""
+    import math
+    n = int(os.environ.get("RT_BENCH_STREAM_TRIANGLES", "10000000"))
+    w, h = 3840, 2160
+    rng = np.random.default_rng(1)
+    size = 100.0 / n ** (1.0 / 3.0)  # mean spacing
+    c = rng.uniform(-50, 50, (n, 1, 3)).astype(np.float32)
+    v = (c + rng.normal(0, 0.6 * size, (n, 3, 3)).astype(np.float32)).astype(np.float32)
+    tris = rt.triangles_from_xyz9(v.reshape(-1, 9))
+    del c, v
+    core = rt.TraceCore(dev.index)
+    core.set_scene(None, tris)
+    del tris
+    cell = float(os.environ.get("RT_BENCH_STREAM_CELL_FACTOR", "1.0")) * size  # the fastest of 1.0 / 1.5 / 2.0 spacings
+    meta, n_cells, n_refs = core.build_grid(cell_size=cell)
+    cam = rt.Camera((0, 0, 75), math.pi, 0.0).to_uniform(0.0, float(h))
+    outs = (torch.empty((w * h, 2), dtype=torch.int32, device=dev), torch.empty((w * h, 2), dtype=torch.int32, device=dev))
+    ref, mov = count_frame(core, cam, w, h, outs)
+    stream = torch.cuda.Stream(device=dev)
+    core.set_stream(stream.cuda_stream)
+    for _ in range(warmup):
+        core.trace_primary(cam, w, h, shadow=True, out_primary=outs[0], out_shadow=outs[1])
+    core.sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(steps):
+        core.trace_primary(cam, w, h, shadow=True, out_primary=outs[0], out_shadow=outs[1])
+    e1.record(stream)
+    core.sync()
+    kernel_ms = e0.elapsed_time(e1) / steps
+    abytes = algorithmic_bytes(ref)
+    mbytes = moved_bytes(mov, w * h)
+    achieved = abytes / (kernel_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": None, "kernel": "k_trace_primary<shadow>", "kernel_ms": kernel_ms, "launches": steps,
+           "workload": f"{n} distinct random triangles (seed 1) in a 100-unit cube, grid cell {cell:.4f} ({list(meta.fine_dims)} cells, "
+                       f"{n_refs} references = {48 * core.trace_refs() / 1e9:.2f} GB of reference records), {w}x{h} primary + "
+                       "shadow rays, camera (0,0,75) looking down -z (every primary ray enters the grid)",
+           "rays_per_frame": ref["rays"], "primary_hits": ref["primary_hits"], "Mrays_per_s": ref["rays"] / kernel_ms / 1e3,
+           "algorithmic_bytes_per_launch": abytes, "cells_visited": ref["cells_visited"], "tri_tests": ref["tri_tests"],
+           "fetched_bytes_per_launch": mbytes, "fetched_GBps": mbytes / (kernel_ms * 1e-3) / 1e9,
+           "cell_records_fetched": mov["cell_records_fetched"], "ref_records_fetched": mov["ref_records_fetched"],
+           "ref_records_staged": mov["ref_records_staged"]}
+    # What reaches HBM (hardware counters of the same command, committed): `frac` is THAT over the HBM peak. The
+    # algorithmic figure stays beside it: neighbouring rays share cells, so most of those bytes are cache hits.
+    out["algorithmic_GBps"] = achieved
+    t = profile_json("r02_streaming_traffic.json")
+    if t and t.get("triangles") == n and abs(t.get("cell_size", cell) - cell) < 1e-3:
+        out["traffic"] = t["bytes_per_launch"]
+        out["achieved"] = t["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+        out["frac"] = out["achieved"] / HBM_PEAK_GBS
+        out["algorithmic_over_traffic"] = abytes / t["bytes_per_launch"]
+        out["traffic_source"] = t["source"]
+        for k in ("l2_hit_rate", "lanes_active_per_valu_instruction", "ta_busy_frac", "valu_issue_frac"):
+            if k in t:
+                out[k] = t[k]
+    else:  # no counter pass for this configuration: nothing to call a fraction of the HBM peak
+        out["achieved"] = None
+        out["frac"] = None
+    core.close()
+    return out
 
 
 def cpu_baseline(xyz9, width, height):
@@ -160,6 +267,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    if os.environ.get("RT_BENCH_LEG") == "streaming" and not multi:  # development / profiling: the second leg alone
+        print(json.dumps({"metric": "streaming leg only", "n_gpus": 1,
+                          "roofline_streaming": streaming_leg(rt, dev, int(os.environ.get("RT_BENCH_STREAM_STEPS", "20")), 3)}), flush=True)
+        return
+
     xyz9 = None
     if WORKLOAD == "massive8k":
         import math
@@ -185,11 +297,10 @@ def main():
     meta, n_cells, n_refs = core.build_grid()
     cam = pose.to_uniform(0.0, float(HEIGHT))
 
-    # the frame's work, counted by the kernel itself (untimed)
-    core.set_collect_stats(True)
-    core.trace_primary(cam, WIDTH, HEIGHT, shadow=True)
-    stats = core.stats()
-    core.set_collect_stats(False)
+    # the frame's work, counted by the kernels themselves (untimed): the reference algorithm's, and what is fetched
+    cnt = (torch.empty((WIDTH * HEIGHT, 2), dtype=torch.int32, device=dev), torch.empty((WIDTH * HEIGHT, 2), dtype=torch.int32, device=dev))
+    stats, moved = count_frame(core, cam, WIDTH, HEIGHT, cnt)
+    del cnt
     rays_per_frame = stats["rays"]
 
     if not multi:
@@ -270,6 +381,18 @@ def main():
         # this is about that many times the time per frame
         per_stream = [(args.steps + FRAMES_IN_FLIGHT - 1 - k) // FRAMES_IN_FLIGHT for k in range(FRAMES_IN_FLIGHT)]
         kernel_ms = float(np.mean([e0.elapsed_time(e1) / n for (e0, e1), n in zip(ev, per_stream) if n]))
+    single_us = None
+    if not multi:  # one frame at a time, nothing else in flight: launch-to-done latency
+        core.set_stream(streams[0].cuda_stream)
+        lat = []
+        for _ in range(30):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(streams[0])
+            core.trace_primary(cam, WIDTH, HEIGHT, shadow=True, out_primary=bufs[0][0], out_shadow=bufs[0][1])
+            e1.record(streams[0])
+            core.sync()
+            lat.append(e0.elapsed_time(e1) * 1e3)
+        single_us = float(np.median(lat[5:]))
     hbm_copy = None
     if not multi:  # what this GPU's HBM delivers on a plain copy (2 GiB read + 2 GiB written), beside the 8 TB/s spec
         a = torch.empty(1 << 29, dtype=torch.float32, device=dev)
@@ -308,35 +431,51 @@ def main():
         }
         if not multi:
             abytes = algorithmic_bytes(stats)
-            achieved = abytes / (kernel_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tpath) and WORKLOAD == "car1080":  # measured on the headline frame only
-                traffic = json.load(open(tpath)).get("k_trace_primary_bytes_per_launch")
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured_copy_GBps": hbm_copy,
-                               "kernel": "k_trace_primary<shadow>", "kernel_ms": kernel_ms,
-                               "concurrent_launches": FRAMES_IN_FLIGHT,
-                               "aggregate_achieved": abytes * args.steps / elapsed / 1e9,
-                               "algorithmic_bytes_per_launch": abytes, "cells_visited": stats["cells_visited"],
-                               "tri_tests": stats["tri_tests"]}
-            vpath = os.path.join(ROOT, "profiles", "valu_counters.json")
-            if os.path.exists(vpath) and WORKLOAD == "car1080":
-                # Beside the HBM figure: the frame is read from the caches (traffic above); what it costs is instruction
-                # issue. The vector pipes of the 1 024 SIMDs take a 64-wide instruction every 2 cycles at best.
-                v = json.load(open(vpath))
-                issue_us = v["SQ_INSTS_VALU_per_launch"] * 2 / (256 * 4) / 2400.0  # at the 2.4 GHz peak engine clock
-                out["roofline"]["valu_issue"] = {"valu_instructions_per_launch": v["SQ_INSTS_VALU_per_launch"],
-                                                 "issue_us_at_2400MHz_2_cycles_per_instruction": issue_us, "frame_us": ms_per_step * 1e3,
-                                                 "frac": issue_us / (ms_per_step * 1e3),
-                                                 "lanes_active_per_instruction": v["lanes_active_per_valu_instruction"]}
+            mbytes = moved_bytes(moved, WIDTH * HEIGHT)
+            frame_s = elapsed / args.steps
+            roof = {"kernel": "k_trace_primary<shadow>", "kernel_ms": kernel_ms, "concurrent_launches": FRAMES_IN_FLIGHT,
+                    "single_frame_us": single_us,
+                    "algorithmic_bytes_per_launch": abytes, "algorithmic_GBps": abytes / frame_s / 1e9,
+                    "cells_visited": stats["cells_visited"], "tri_tests": stats["tri_tests"],
+                    "fetched_bytes_per_launch": mbytes, "fetched_GBps": mbytes / frame_s / 1e9,
+                    "cell_records_fetched": moved["cell_records_fetched"], "ref_records_fetched": moved["ref_records_fetched"],
+                    "ref_records_staged": moved["ref_records_staged"], "measured_copy_GBps": hbm_copy,
+                    "note": ("algorithmic bytes are the reference algorithm's (every list entry of every visited cell, 8 B per cell, "
+                             "40 B per candidate, 8 B per ray); fetched bytes are what the timed kernel requests from the memory "
+                             "system; traffic is what reached HBM (hardware counters). Rates are per frame of the timed region "
+                             "(launches overlap), not per launch.")}
+            t = profile_json("r02_headline_traffic.json") if WORKLOAD == "car1080" else None
+            v = profile_json("r02_headline_valu.json") if WORKLOAD == "car1080" else None
+            if t:
+                roof["traffic"] = t["bytes_per_launch"]
+                roof["hbm_traffic_frac"] = t["bytes_per_launch"] / frame_s / 1e9 / HBM_PEAK_GBS
+                roof["algorithmic_over_traffic"] = abytes / t["bytes_per_launch"]
+                roof["traffic_source"] = t["source"]
+            else:
+                roof["traffic"] = None
+            if v:
+                # the scene is read from the caches; what a frame costs is instruction issue
+                ginstr = v["SQ_INSTS_VALU_per_launch"] / frame_s / 1e9
+                roof.update({"bound": "valu_issue", "achieved": ginstr, "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s",
+                             "frac": ginstr / VALU_PEAK_GINSTR, "valu_instructions_per_launch": v["SQ_INSTS_VALU_per_launch"],
+                             "salu_instructions_per_launch": v["SQ_INSTS_SALU_per_launch"],
+                             "lanes_active_per_valu_instruction": v["lanes_active_per_valu_instruction"],
+                             "counter_source": v["source"]})
+            else:  # no counter pass committed for this workload: the HBM view only, on measured traffic where there is one
+                a = (roof["traffic"] or 0) / frame_s / 1e9
+                roof.update({"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS})
+            out["roofline"] = roof
             if WORKLOAD != "car1080":
-                out["roofline"]["note"] = ("algorithmic bytes are those of the reference's full cell lists (counting kernels); "
-                                           "the timed kernels leave out exact duplicate triangles, config.trace_refs of config.cell_refs")
+                out["roofline"]["note"] += (" The timed kernels leave out exact duplicate triangles (config.trace_refs of "
+                                            "config.cell_refs); the fetched figure counts what they walk.")
+            if os.environ.get("RT_BENCH_LEG", "both") != "headline" and WORKLOAD == "car1080":
+                core.close()
+                out["roofline_streaming"] = streaming_leg(rt, dev, int(os.environ.get("RT_BENCH_STREAM_STEPS", "20")), 3)
             if not args.no_cpu_baseline and xyz9 is not None:
                 out["cpu_baseline"] = cpu_baseline(xyz9, WIDTH, HEIGHT)
         print(json.dumps(out), flush=True)
-    core.close()
+    if core._h:
+        core.close()
     if multi:
         dist.destroy_process_group()
 

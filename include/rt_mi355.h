@@ -68,7 +68,10 @@ typedef struct rt_params {
     float fov;                     /* 0.785398        raytracer_unified.wgsl:4,643 */
     float light_direction[3];      /* (0.5,-1,0.3)    raytracer_unified.wgsl:5 */
     float shadow_offset;           /* 0.001           raytracer_unified.wgsl:687 */
-    uint32_t collect_stats;        /* 0; 1 = count cells/candidates (slower kernels) */
+    uint32_t collect_stats;        /* 0; 1 = count the cells and candidates of the REFERENCE algorithm (every list
+                                      entry, no re-test skipping: slower kernels); 2 = count what the shipped kernels
+                                      fetch (re-test skipping, duplicate removal, look-ahead, LDS staging as timed):
+                                      rays and hits plus the three *_records_* fields of rt_stats */
     uint32_t skip_duplicate_triangles; /* 1: grids built by rt_build_grid leave a triangle out of the records the
                                          trace walks when a triangle with a lower id has bit-identical vertices and
                                          no alpha rule of its own: the copy is met right after the original in every
@@ -106,6 +109,10 @@ typedef struct rt_stats {
     uint64_t cells_visited; /* DDA iterations (cell records read) */
     uint64_t tri_tests;     /* Moller-Trumbore candidates tested */
     uint64_t box_tests;     /* slab candidates tested (moving-box pre-pass included) */
+    /* collect_stats = 2 only (0 otherwise): what the trace kernels asked the memory system for */
+    uint64_t cell_records_fetched; /* 8-byte cell records loaded, summed over lanes */
+    uint64_t ref_records_fetched;  /* 48-byte reference records loaded by a lane for itself (look-ahead included) */
+    uint64_t ref_records_staged;   /* 48-byte reference records copied into LDS once for a whole wave */
 } rt_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -358,7 +365,7 @@ int rt_assemble_frames(rt_ctx* ctx, const uint8_t* gathered, uint32_t pixel_form
  * primary_hits, shadow_rays and shadow_hits only: cells_visited, tri_tests and box_tests read 0 after them (the
  * picture kernels have no counting instantiation). */
 int rt_get_stats(rt_ctx* ctx, rt_stats* stats);
-int rt_set_collect_stats(rt_ctx* ctx, int enabled);
+int rt_set_collect_stats(rt_ctx* ctx, int mode); /* 0, 1 or 2: params.collect_stats */
 
 /* ---- primitive routines, all pairs ---------------------------------------------------- */
 

@@ -417,13 +417,13 @@ int make_shard(rt_ctx* c, uint32_t w, uint32_t h, const rt_shard* sh, ShardMap* 
 }
 
 int zero_stats(rt_ctx* c) {
-    RT_HIP(c, c->stats.reserve(8 * sizeof(unsigned long long)));
-    RT_HIP(c, hipMemsetAsync(c->stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, c->stats.reserve(16 * sizeof(unsigned long long)));
+    RT_HIP(c, hipMemsetAsync(c->stats.p, 0, 16 * sizeof(unsigned long long), c->stream));
     return RT_OK;
 }
 
 int fetch_stats(rt_ctx* c) {
-    unsigned long long v[8];
+    unsigned long long v[16];
     RT_HIP(c, hipMemcpyAsync(v, c->stats.p, sizeof(v), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->last_stats.rays = v[0];
@@ -433,6 +433,9 @@ int fetch_stats(rt_ctx* c) {
     c->last_stats.cells_visited = v[4];
     c->last_stats.tri_tests = v[5];
     c->last_stats.box_tests = v[6];
+    c->last_stats.cell_records_fetched = v[7];
+    c->last_stats.ref_records_fetched = v[8];
+    c->last_stats.ref_records_staged = v[9];
     return RT_OK;
 }
 
@@ -444,7 +447,7 @@ bool wide_grid(const DevScene& s) {
 // Kernel variants: WGSL (constant set), SHADOW / ANY, BOXES (scene has boxes), TEX (hits decided by a texture's
 // alpha). The counting build is the general one (with the box path); so is the build for grids of 4 GiB and more.
 template <bool WGSL, bool SHADOW>
-void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* op,
+void launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* op,
                     uint2* os) {
     unsigned long long* st = c->stats.as<unsigned long long>();
 #ifdef RT_EXPERIMENTS
@@ -465,6 +468,10 @@ void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const D
                 }
                 return;
             }
+            if (vn == 70) {  // the 80-scalar-register build of the shipped kernel
+                hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os);
+                return;
+            }
             switch (vn) {
 #define RT_VAR(N) case N: hipLaunchKernelGGL((k_trace_primary_var<N>), dim3(grid.x * (256 / VarCfg<N>::threads)), dim3(VarCfg<N>::threads), 0, c->stream, s, f, m, op, os); return;
                 RT_VARIANT_LIST
@@ -473,48 +480,53 @@ void launch_primary(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const D
         }
     }
 #endif
+    // the two counting builds (1: the reference's work, 2: this library's fetches) are the general kernels
     if (wide_grid(s)) {
-        if (stats)
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        if (stats == 2)
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 2, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        else if (stats)
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 1, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
         else
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+    } else if (stats == 2) {
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 2, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+    } else if (stats) {
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 1, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
     } else if (c->tex_mode == 2) {  // hits decided by a texture's alpha: the general kernel with the material path
-        if (stats)
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
-        else if (s.nb != 0)
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        if (s.nb != 0)
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
         else
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, false, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
-    } else if (stats)
-        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
-    else if (s.nb != 0)
-        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+    } else if (s.nb != 0)
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
     else
-        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, false, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
 }
 
 template <bool WGSL, bool ANY>
-void launch_rays(rt_ctx* c, bool stats, dim3 grid, const DevScene& s, const float* o, const float* d, uint32_t n,
+void launch_rays(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const float* o, const float* d, uint32_t n,
                  uint2* out) {
     unsigned long long* st = c->stats.as<unsigned long long>();
     if (wide_grid(s)) {
-        if (stats)
-            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+        if (stats == 2)
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 2, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+        else if (stats)
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 1, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
         else
-            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+    } else if (stats == 2) {
+        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 2, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+    } else if (stats) {
+        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 1, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
     } else if (c->tex_mode == 2) {
-        if (stats)
-            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
-        else if (s.nb != 0)
-            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+        if (s.nb != 0)
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
         else
-            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, false, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
-    } else if (stats)
-        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, true, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
-    else if (s.nb != 0)
-        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+            hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, false, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+    } else if (s.nb != 0)
+        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
     else
-        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, false, false>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+        hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, false>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
 }
 
 // Stage a host array on the device (or pass a device pointer through).
@@ -685,11 +697,14 @@ extern "C" int rt_sync(rt_ctx* c) {
 
 extern "C" int rt_set_collect_stats(rt_ctx* c, int enabled) {
     if (int r = use(c)) return r;
-    const uint32_t v = enabled ? 1u : 0u;
+    if (enabled < 0 || enabled > 2) return fail(c, RT_ERR_INVALID, "rt_set_collect_stats: mode %d (0, 1 or 2)", enabled);
+    const uint32_t v = (uint32_t)enabled;
     if (v == c->params.collect_stats) return RT_OK;
+    const bool full_lists_before = c->params.collect_stats == 1, full_lists_now = v == 1;
     c->params.collect_stats = v;
-    // the counting kernels walk the reference's full lists
-    if (c->has_grid && c->grid_built && c->params.skip_duplicate_triangles && c->dup_state != 0) {
+    // mode 1 walks the reference's full lists, modes 0 and 2 the lists with duplicate triangles left out
+    if (full_lists_before != full_lists_now && c->has_grid && c->grid_built && c->params.skip_duplicate_triangles &&
+        c->dup_state != 0) {
         if (int r = scene_barrier(c)) return r;
         RT_HIP(c, hipStreamSynchronize(c->stream));
         if (int r = rebuild_trace_records(c)) return r;
@@ -942,7 +957,7 @@ static int trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t width, ui
     } else if (int r = update_box_frame(c, cam)) {
         return r;
     }
-    const bool stats = c->params.collect_stats != 0;
+    const int stats = (int)c->params.collect_stats;
     if (stats)
         if (int r = zero_stats(c)) return r;
 
@@ -1000,7 +1015,7 @@ extern "C" int rt_trace_rays(rt_ctx* c, const CameraUniform* cam, const float* o
         d_out = c->out_p.as<uint2>();
     }
     if (int r = update_box_frame(c, cam)) return r;
-    const bool stats = c->params.collect_stats != 0;
+    const int stats = (int)c->params.collect_stats;
     if (stats)
         if (int r = zero_stats(c)) return r;
     const DevScene s = make_scene(c);

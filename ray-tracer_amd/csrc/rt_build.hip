@@ -370,7 +370,7 @@ int rebuild_trace_records(rt_ctx* c) {
     const uint32_t nb = c->grid_nb, nt = c->nt, n_refs = c->n_refs, n_cells = c->n_cells;
     // Only for lists this library built (lowest ids survive the cap), when the shader's own cap does not cut them
     // further, and not for the counting kernels, which walk what the reference walks.
-    const bool dedup = c->grid_built && c->params.skip_duplicate_triangles && !c->params.collect_stats && nt > 1 && n_refs > 0 &&
+    const bool dedup = c->grid_built && c->params.skip_duplicate_triangles && c->params.collect_stats != 1 && nt > 1 && n_refs > 0 &&
                        c->params.max_objects_per_cell >= c->build_cap && c->dup_state != 0;
     if (dedup) {
         RT_HIP(c, c->dd_keys.reserve((size_t)nt * 8));

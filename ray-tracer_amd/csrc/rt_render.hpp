@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, SINGLE ? 8 : RT_RENDER_WAVES) void k_render(De
     const bool live = in_tile && px < f.width && py < f.height;
 
     uint32_t rgba = 0;
-    Counters ctr{0, 0, 0, 0};
+    Counters ctr{0, 0, 0, 0, 0, 0, 0};
     // rays, primary hits, shadow rays, shadow hits of this pixel: at most 8 bounces, so a byte each in one register
     uint32_t counts = 0;
     if (live) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, SINGLE ? 8 : RT_RENDER_WAVES) void k_render(De
             const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
             HitRec h;
             counts += 1u;
-            if (!trace_ray<WGSL, false, false, BOXES, TEX, WIDE>(s, o, rd, h, ctr)) {
+            if (!trace_ray<WGSL, false, 0, BOXES, TEX, WIDE>(s, o, rd, h, ctr)) {
                 // sky (:591-596)
                 const float t = (d.y + 1.0f) * 0.5f;
                 acc = acc + mix(v3(0.3f, 0.5f, 0.7f), v3(0.5f, 0.7f, 1.0f), t) * mult;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, SINGLE ? 8 : RT_RENDER_WAVES) void k_render(De
                 if (dot(nf, d) > 0.0f) nf = neg(nf);
                 HitRec oh;
                 counts += 0x10001u;
-                if (trace_ray<WGSL, true, false, BOXES, TEX, WIDE>(s, pos + nf * f.shadow_offset, f.shadow, oh, ctr)) {
+                if (trace_ray<WGSL, true, 0, BOXES, TEX, WIDE>(s, pos + nf * f.shadow_offset, f.shadow, oh, ctr)) {
                     counts += 1u << 24;
                     diffuse = 0.0f;
                 }

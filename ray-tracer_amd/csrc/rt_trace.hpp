@@ -96,6 +96,9 @@ __device__ inline uint32_t shard_tile(const ShardMap& m, uint32_t lt) {
 
 struct Counters {
     uint32_t cells, tri, box, steps;
+    // STATS == 2: what this lane asked the memory system for - cell records (8 bytes each), reference records read
+    // directly (48 bytes each, the look-ahead record included) and reference records copied into LDS for the wave
+    uint32_t cell_recs, ref_recs, staged_recs;
 };
 
 struct HitRec {
@@ -159,8 +162,9 @@ __device__ inline float4* wave_stage() {
 //     faces of this cell a ray can arrive having already met the object (see k_ref_masks in rt_build.hip);
 //     it is 0 (never skip) for grids supplied by the caller.
 // ANY: stop at the first accepted intersection. BOXES: scene has boxes (pre-pass + box candidates).
-// STATS: count what the REFERENCE algorithm does (no skipping), for parity of the counters and for the
-// algorithmic byte count. Returns true on a hit.
+// STATS: 0 = none. 1 = count what the REFERENCE algorithm does (no skipping), for parity of the counters and for the
+// algorithmic byte count. 2 = count what THIS kernel fetches (skipping, look-ahead and LDS staging as shipped): the
+// bytes the timed kernels request from the memory system. Returns true on a hit.
 // TEX: the scene has materials whose alpha comes from a texture; a reference to such a triangle carries its material
 // in the spare word of the third quad, and a geometric hit that would become the closest one is first put to the
 // shader's alpha rule (raytracer_unified.wgsl:303-316) at its interpolated uv. (The shader applies the rule inside
@@ -168,9 +172,9 @@ __device__ inline float4* wave_stage() {
 // WIDE: the reference records or the cell array span 4 GiB or more. A buffer descriptor forms its byte offset
 // (index * stride) in 32 bits, so such arrays are read through plain 64-bit pointers instead.
 // X: development switch (0 in every shipped instantiation).
-template <bool WGSL, bool ANY, bool STATS, bool BOXES, bool TEX = false, bool WIDE = false, int X = 0>
+template <bool WGSL, bool ANY, int STATS, bool BOXES, bool TEX = false, bool WIDE = false, int X = 0>
 __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitRec& out, Counters& ctr) {
-    constexpr bool SKIP = !STATS;
+    constexpr bool SKIP = STATS != 1;
     float closest = 1e10f;
     uint32_t best_id = MISS, best_ref = MISS;
     const V3 d = rd.d, inv = rd.inv;
@@ -185,6 +189,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             return buf_load16<16 * Q>(refs_d, r);
     };
     auto cell_rec = [&](uint32_t idx) -> uint2 {
+        if (STATS == 2) ctr.cell_recs++;
         if constexpr (WIDE)
             return s.cells[idx];
         else
@@ -193,15 +198,15 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
     using Q2 = std::integral_constant<int, 2>;
-    if (STATS) ctr.steps = 0;
+    if (STATS == 1) ctr.steps = 0;
 
     // moving boxes are tested directly, before the grid (:442-461)
     if (BOXES) {
         for (uint32_t i = s.moving_start; i < s.nb; ++i) {
-            if (STATS) ctr.steps++;
+            if (STATS == 1) ctr.steps++;
             const float4 b0 = s.box_frame[4 * i], b1 = s.box_frame[4 * i + 1];
             if (!(__float_as_uint(b0.w) & BOX_CULLED_PREPASS)) {
-                if (STATS) ctr.box++;
+                if (STATS == 1) ctr.box++;
                 const float t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
                 if (t >= 0.0f && t < closest) {
                     closest = t;
@@ -261,7 +266,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             const float4 b0 = s.box_frame[4 * id], b1 = s.box_frame[4 * id + 1];
             float t = -1.0f;
             if (!(__float_as_uint(b0.w) & BOX_CULLED_GRID)) {
-                if (STATS) ctr.box++;
+                if (STATS == 1) ctr.box++;
                 t = slab(o, inv, v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z));
             }
             if (t >= 0.0f && t < closest) {
@@ -271,7 +276,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
                 return ANY;
             }
         } else {
-            if (STATS && id != REF_INVALID) ctr.tri++;
+            if (STATS == 1 && id != REF_INVALID) ctr.tri++;
             const float t = moller_trumbore_pk<WGSL>(rp, c0, c1, c2);
             if (t > 0.0f && t < closest && id < REF_INVISIBLE) {
                 if (TEX && __float_as_uint(c2.w) != 0u) {
@@ -312,6 +317,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
                 for (uint32_t base = 0; base < n0; base += STAGE_RECORDS) {  // lists longer than the buffer: in pieces
                     const uint32_t cnt = n0 - base < STAGE_RECORDS ? n0 - base : STAGE_RECORDS;
                     for (uint32_t k = rank; k < cnt; k += n_act) {
+                        if (STATS == 2) ctr.staged_recs++;
                         mine[3 * k] = ref_quad(r0 + base + k, Q0{});
                         mine[3 * k + 1] = ref_quad(r0 + base + k, Q1{});
                         mine[3 * k + 2] = ref_quad(r0 + base + k, Q2{});
@@ -329,11 +335,14 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         }
         const uint32_t r_end = r + n;
         float4 a0 = ref_quad(r, Q0{}), a1 = ref_quad(r, Q1{}), a2 = ref_quad(r, Q2{});
+        if (STATS == 2) ctr.ref_recs++;
         for (;;) {
             const float4 b0 = ref_quad(r + 1, Q0{}), b1 = ref_quad(r + 1, Q1{}), b2 = ref_quad(r + 1, Q2{});
+            if (STATS == 2) ctr.ref_recs++;
             if (test(a0, a1, a2, r)) break;
             if (++r == r_end) break;
             a0 = ref_quad(r + 1, Q0{}), a1 = ref_quad(r + 1, Q1{}), a2 = ref_quad(r + 1, Q2{});
+            if (STATS == 2) ctr.ref_recs++;
             if (test(b0, b1, b2, r)) break;
             if (++r == r_end) break;
         }
@@ -345,7 +354,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         // x + y*gx + z*gx*gy (:406-409) then names some other cell, or none, until a step brings the ray inside,
         // and a step whose target is outside ends the traversal (:568-583). Rare, so it is restated literally.
         for (uint32_t i = 0; i < s.max_steps; ++i) {
-            if (STATS) {
+            if (STATS == 1) {
                 ctr.steps++;
                 ctr.cells++;
             }
@@ -387,6 +396,48 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     // counters and no range check on the index.
     uint32_t idx = (cx + 1u) + (cy + 1u) * s.px + (cz + 1u) * s.pxy;
     uint2 cell = cell_rec(idx);
+    if constexpr (X == 3) {
+        // Interleaved form: in every trip of ONE loop a lane either tests the next candidate of its current cell or,
+        // when that list is done, leaves the cell (early-out test, step, next cell record). Lanes of a wave that sit
+        // in cells with lists of different lengths - or in empty cells - no longer wait for the longest list at every
+        // step: a lane in empty space keeps stepping while its neighbours test candidates. Per lane the sequence of
+        // tests, comparisons and steps is exactly that of the nested loops below, so the result is the same.
+        uint32_t left = s.max_steps;
+        uint32_t r = cell.x, r_end = cell.x + cell.y;
+        bool alive = left != 0 && cell.y != CELL_SENTINEL;
+        while (alive) {
+            if (r < r_end) {
+                const float4 a0 = ref_quad(r, Q0{}), a1 = ref_quad(r, Q1{}), a2 = ref_quad(r, Q2{});
+                if (STATS == 2) ctr.ref_recs++;
+                const bool accepted = test(a0, a1, a2, r);
+                ++r;
+                if (ANY && accepted) alive = false;
+            } else {
+                const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
+                const bool ay = !ax && t_max.y < t_max.z;
+                const bool az = !ax && !ay;
+                const float t_exit = fminf(fminf(t_max.x, t_max.y), t_max.z);
+                if (STATS == 1) {
+                    ctr.steps++;
+                    ctr.cells++;
+                }
+                const bool hit = best_id != MISS;
+                --left;
+                const bool stop = (ANY & hit) | (hit & (closest < t_exit)) | (left == 0);
+                idx += ax ? dix : (ay ? diy : diz);
+                arrival = ax ? mx : (ay ? my : mz);
+                t_max.x += ax ? t_delta.x : 0.0f;
+                t_max.y += ay ? t_delta.y : 0.0f;
+                t_max.z += az ? t_delta.z : 0.0f;
+                cell = cell_rec(idx);
+                alive = !stop && cell.y != CELL_SENTINEL;
+                r = cell.x;
+                r_end = cell.x + cell.y;
+            }
+        }
+        out = HitRec{closest, best_id, best_ref};
+        return best_id != MISS;
+    }
     // One exit test per step: leaving the grid, the early-out and the step limit all end the loop through the
     // sentinel count (a stopped ray's next record is overwritten with it). Three separate exits cost a divergent
     // break each - exec-mask bookkeeping in scalar instructions - on every step of every ray; the one record fetched
@@ -400,7 +451,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         const bool ay = !ax && t_max.y < t_max.z;
         const bool az = !ax && !ay;
         const float t_exit = fminf(fminf(t_max.x, t_max.y), t_max.z);
-        if (STATS) {
+        if (STATS == 1) {
             ctr.steps++;
             ctr.cells++;
         }
@@ -453,9 +504,9 @@ __device__ inline V3 primary_dir(const DevFrame& f, uint32_t px, uint32_t py) {
 // Wave-level sum of per-lane counters, one atomic per wave per counter.
 __device__ inline void flush_stats(unsigned long long* stats, unsigned long long rays, unsigned long long phits,
                                    unsigned long long srays, unsigned long long shits, const Counters& c) {
-    unsigned long long v[7] = {rays, phits, srays, shits, c.cells, c.tri, c.box};
+    unsigned long long v[10] = {rays, phits, srays, shits, c.cells, c.tri, c.box, c.cell_recs, c.ref_recs, c.staged_recs};
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 10; ++k) {
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[k], x);
@@ -467,9 +518,9 @@ __device__ inline void flush_stats(unsigned long long* stats, unsigned long long
 // different XCDs at the same time: cheap (sky) and expensive (dense geometry) image regions are spread
 // evenly over the chip. (Giving each XCD one contiguous band of the image instead left most XCDs idle
 // behind the one that owned the geometry: 30 % average occupancy on the headline frame.)
-template <bool WGSL, bool SHADOW, bool STATS, bool BOXES, bool TEX = false, bool WIDE = false>
-__global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
-                                                       uint2* __restrict__ out_s, unsigned long long* stats) {
+template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX, bool WIDE>
+__device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* __restrict__ out_p,
+                                           uint2* __restrict__ out_s, unsigned long long* stats) {
     const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
     const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;  // 16x16 blocks per tile
     const uint32_t blk_per_tile = blk_x * blk_y;
@@ -483,7 +534,7 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
     const bool live = in_tile && px < f.width && py < f.height;
 
     uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
-    Counters ctr{0, 0, 0, 0};
+    Counters ctr{0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_rays = 0, n_ph = 0, n_sr = 0, n_sh = 0;
     if (live) {
         const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
@@ -517,13 +568,28 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
     if (STATS) flush_stats(stats, n_rays, n_ph, n_sr, n_sh, ctr);
 }
 
+template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX = false, bool WIDE = false>
+__global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
+                                                       uint2* __restrict__ out_s, unsigned long long* stats) {
+    trace_primary_block<WGSL, SHADOW, STATS, BOXES, TEX, WIDE>(s, f, m, out_p, out_s, stats);
+}
+
+// The same kernel for triangle-only scenes without counters, held to 80 scalar registers: a CU admits eight 256-thread
+// workgroups only up to 80 (seven up to 96), and the general kernel holds 93. Eight scalars live in a vector register's
+// lanes instead (63 vector registers, still eight waves per SIMD).
+template <bool WGSL, bool SHADOW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_trace_primary_lean(
+    DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p, uint2* __restrict__ out_s) {
+    trace_primary_block<WGSL, SHADOW, 0, false, false, false>(s, f, m, out_p, out_s, nullptr);
+}
+
 // Explicit ray list: one lane per ray.
-template <bool WGSL, bool ANY, bool STATS, bool BOXES, bool TEX = false, bool WIDE = false>
+template <bool WGSL, bool ANY, int STATS, bool BOXES, bool TEX = false, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __restrict__ origins,
                                                     const float* __restrict__ dirs, uint32_t n,
                                                     uint2* __restrict__ out, unsigned long long* stats) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    Counters ctr{0, 0, 0, 0};
+    Counters ctr{0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_rays = 0, n_hit = 0;
     if (i < n) {
         HitRec h;
@@ -543,9 +609,9 @@ __global__ void k_debug_pixel(DevScene s, DevFrame f, uint32_t px, uint32_t py, 
     const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
     const V3 d = primary_dir(f, px, py);
     HitRec h;
-    Counters ctr{0, 0, 0, 0};
+    Counters ctr{0, 0, 0, 0, 0, 0, 0};
     const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
-    const bool hit = trace_ray<WGSL, false, true, true, true, WIDE>(s, o, rd, h, ctr);
+    const bool hit = trace_ray<WGSL, false, 1, true, true, WIDE>(s, o, rd, h, ctr);
     for (int k = 0; k < 20; ++k) info20[k] = 0.0f;
     info20[0] = o.x, info20[1] = o.y, info20[2] = o.z;
     info20[3] = hit ? 1.0f : 0.0f;

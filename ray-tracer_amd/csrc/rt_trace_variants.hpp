@@ -6,6 +6,8 @@
 //   body 1..9   trace_ray_x<body> below (whatever is being tried); body 2 = trace_ray without LDS staging
 //   0x          four waves per workgroup (shipped)      1x  one wave per workgroup
 //   2x          __launch_bounds__(256, 8)               3x  per-wave start/end timestamps into g_wave_t
+//   6x          at most 80 scalar registers (eight 256-thread workgroups per CU are admitted up to 80; the shipped kernel
+//               holds 93, which admits seven)
 //   4x          persistent waves: 2048 workgroups (every wave slot of the chip once), each wave takes the next 8x8
 //               pixel block from an atomic counter until none is left
 //   5x          the same, blocks handed out in the order of g_order (e.g. most expensive first)
@@ -17,8 +19,8 @@ namespace rt {
 // experiment slot: by default the shipped function
 template <int BODY, bool ANY>
 __device__ inline bool trace_ray_x(const DevScene& s, V3 o, const RayDir& rd, HitRec& out) {
-    Counters ctr{0, 0, 0, 0};
-    return trace_ray<false, ANY, false, false, false, false, BODY>(s, o, rd, out, ctr);
+    Counters ctr{};
+    return trace_ray<false, ANY, 0, false, false, false, BODY>(s, o, rd, out, ctr);
 }
 
 __device__ unsigned long long g_wave_t[2 * 65536];  // s_memrealtime (100 MHz) at wave start / end
@@ -44,6 +46,12 @@ __global__ __launch_bounds__(VarCfg<VARIANT>::threads, VarCfg<VARIANT>::min_wave
     const uint32_t gw = VarCfg<VARIANT>::threads == 64 ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);  // global wave
     trace_block<VARIANT>(s, f, m, out_p, out_s, gw);
 }
+#define RT_SGPR80(N)                                                                                                     \
+    template <>                                                                                                          \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_trace_primary_var<N>(                  \
+        DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p, uint2* __restrict__ out_s) {                      \
+        trace_block<N>(s, f, m, out_p, out_s, blockIdx.x * 4 + (threadIdx.x >> 6));                                      \
+    }
 
 // Persistent waves: every wave reaches the exit test (chunk >= n_chunks) after finitely many blocks. A wave takes
 // CHUNK queue positions per atomic (same-address device-scope atomics complete at about one per 15 ns on this chip:
@@ -69,6 +77,8 @@ __global__ __launch_bounds__(256) void k_trace_primary_persist(DevScene s, DevFr
     }
 }
 
+RT_SGPR80(60)
+
 template <int VARIANT>
 __device__ inline void trace_block(const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* __restrict__ out_p,
                                    uint2* __restrict__ out_s, uint32_t gw) {
@@ -88,10 +98,10 @@ __device__ inline void trace_block(const DevScene& s, const DevFrame& f, const S
     const bool in_tile = lx < m.tile_w && ly < m.tile_h;
     const bool live = in_tile && px < f.width && py < f.height;
     uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
-    Counters ctr{0, 0, 0, 0};
+    Counters ctr{};
     auto trace = [&](V3 o, const RayDir& rd, HitRec& h, auto any) -> bool {
         constexpr bool ANY = decltype(any)::value;
-        if constexpr (BODY == 0) return trace_ray<false, ANY, false, false>(s, o, rd, h, ctr);
+        if constexpr (BODY == 0) return trace_ray<false, ANY, 0, false>(s, o, rd, h, ctr);
         else return trace_ray_x<BODY, ANY>(s, o, rd, h);
     };
     if (live) {

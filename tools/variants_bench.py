@@ -18,13 +18,37 @@ variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0
 rounds, steps = 7, 50
 W, H = 1920, 1080
 core = rt.TraceCore(0)
-if os.environ.get("RT_MODEL") == "phoenix":  # the animated model's bind pose, the camera of tools/bench_configs.py
+MODEL = os.environ.get("RT_MODEL", "car")
+CELL = 0.0
+if MODEL.startswith("stream"):  # bench.py's streaming leg: n distinct random triangles, camera inside the volume
+    import math
+    n = int(MODEL.split(":")[1]) if ":" in MODEL else 10000000
+    W, H = 3840, 2160
+    rounds, steps = 3, 5
+    rng = np.random.default_rng(1)
+    size = 100.0 / n ** (1.0 / 3.0)
+    c = rng.uniform(-50, 50, (n, 1, 3)).astype(np.float32)
+    v = (c + rng.normal(0, 0.6 * size, (n, 3, 3)).astype(np.float32)).astype(np.float32)
+    core.set_scene(None, rt.triangles_from_xyz9(v.reshape(-1, 9)))
+    del c, v
+    CELL = float(os.environ.get("RT_CELL_FACTOR", "2.0")) * size
+    cam = rt.Camera((0, 0, 75), math.pi, 0.0).to_uniform(0.0, float(H))
+elif MODEL.startswith("massive"):  # the reference's benchmark scene, every list entry tested or duplicates left out
+    import math
+    from ray_tracer_amd import workloads
+    n = int(MODEL.split(":")[1]) if ":" in MODEL else 100000
+    W, H = 3840, 2160
+    rounds, steps = 3, 5
+    core.set_scene(None, workloads.generate_test_triangles(n))
+    CELL = float(os.environ.get("RT_CELL", "16.0"))
+    cam = rt.Camera((0, 0, 75), math.pi, 0.0).to_uniform(0.0, float(H))
+elif MODEL == "phoenix":  # the animated model's bind pose, the camera of tools/bench_configs.py
     core.set_scene(None, rt.triangles_from_xyz9(np.load(os.path.join(ROOT, "tests/golden/phoenix_tris.npy"))))
     cam = rt.Camera((-300, 250, 600), 2.7, -0.2).to_uniform(0.0, float(H))
 else:
     core.set_scene(None, rt.triangles_from_xyz9(np.load(os.path.join(ROOT, "tests/golden/car_tris.npy"))))
     cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
-core.build_grid()
+core.build_grid(cell_size=CELL)
 p = torch.empty((W * H, 2), dtype=torch.int32, device="cuda")
 s = torch.empty_like(p)
 os.environ.pop("RT_VARIANT", None)

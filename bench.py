@@ -169,6 +169,28 @@ def streaming_leg(rt, dev, steps, warmup):
     return out
 
 
+def same_route_single_gpu(core, sharding, cam, dev, steps):
+    """ms per frame of ONE GPU running the route the N > 1 lines time - every tile of the frame rendered as the shaded
+    picture (direct lighting with the shadow-ray term: the same primary + shadow rays), groups of GROUP frames, 3 bytes
+    per pixel, assembled to RGBA8 - without a collective. The N > 1 lines are compared with THIS, not with the
+    hit-record figure of the N = 1 line, which is another kernel and another output."""
+    sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, 0, 1, dev, shadow=True, mode="rgba", frames_in_flight=1,
+                               max_bounces=1, collective=False)
+    sh.native_comm = False
+    sh.enable_groups(GROUP, GROUPS_IN_FLIGHT, rgb8=True)
+    cams = [cam] * GROUP
+    for _ in range(2):
+        sh.trace_group(cams)
+    sh.synchronize()
+    n_groups = max(2, steps // GROUP)
+    t0 = time.perf_counter()
+    for _ in range(n_groups):
+        sh.trace_group(cams)
+    sh.synchronize()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (n_groups * GROUP) * 1e3
+
+
 def cpu_baseline(xyz9, width, height):
     """The reference's CPU trace path (binned-SAH BVH, recursive both-children traversal, Moller-Trumbore
     leaves; examples/massive_benchmark.rs:62-98,226-270) on this frame's primary + shadow rays, all host
@@ -290,10 +312,16 @@ def main():
                 "(models/no_animation, 3132 triangles, flattened to a fixture); no file or dataset is read in the timed region")
         workload = ("configs[1]: static model, 1920x1080 primary rays through the DDA uniform grid "
                     "+ one shadow ray per primary hit, SCENE=gltf start camera")
-    if multi:  # scene replicated by one RCCL broadcast, grid binned locally on every GPU
-        _, tris = sharding.broadcast_scene(np.zeros(0, rt.BOX_DTYPE) if rank == 0 else None, tris, dev)
     core = rt.TraceCore(local_rank)
-    core.set_scene(None, tris)
+    if multi:
+        # scene replicated by ONE RCCL broadcast through the C ABI (rt_comm_init + rt_broadcast_scene: device to
+        # device, straight into the scene buffers), grid binned locally on every GPU. The rehearsal on one GPU cannot
+        # have an RCCL communicator (two ranks on one device are refused): torch.distributed over gloo stands in.
+        if not rehearsal:
+            sharding.init_comm(core, rank, world)
+        sharding.replicate_scene(core, np.zeros(0, rt.BOX_DTYPE) if rank == 0 else None, tris)
+    else:
+        core.set_scene(None, tris)
     meta, n_cells, n_refs = core.build_grid()
     cam = pose.to_uniform(0.0, float(HEIGHT))
 
@@ -324,7 +352,7 @@ def main():
         wenv = os.environ.get("RT_BENCH_WEIGHTS", "")
         weights = None if wenv == "equal" else [int(k) for k in wenv.split(",")] if wenv else sharding.gatherer_weights(world)
         sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
-                                   frames_in_flight=1, max_bounces=1, collective=True, weights=weights)
+                                   frames_in_flight=1, max_bounces=1, collective=True, weights=weights, host_gather=rehearsal)
         sh.enable_groups(GROUP, GROUPS_IN_FLIGHT, rgb8=os.environ.get("RT_BENCH_WIRE", "rgb") == "rgb")  # the constant alpha byte stays at home
         if os.environ.get("RT_BENCH_TRACE"):  # development: where every rank is, every few seconds
             import threading
@@ -354,6 +382,9 @@ def main():
                 pending.clear()
             sh.synchronize()
 
+    base_ms = None
+    if multi and rank == 0:  # the single-GPU figure of the same route, measured while the other ranks wait
+        base_ms = same_route_single_gpu(core, sharding, cam, dev, max(64, args.steps))
     for _ in range(args.warmup):
         step()
     sync()
@@ -393,6 +424,8 @@ def main():
             core.sync()
             lat.append(e0.elapsed_time(e1) * 1e3)
         single_us = float(np.median(lat[5:]))
+    if not multi:
+        base_ms = same_route_single_gpu(core, sharding, cam, dev, max(64, args.steps))
     hbm_copy = None
     if not multi:  # what this GPU's HBM delivers on a plain copy (2 GiB read + 2 GiB written), beside the 8 TB/s spec
         a = torch.empty(1 << 29, dtype=torch.float32, device=dev)
@@ -429,6 +462,14 @@ def main():
                        "parallelism": "single GPU" if not multi else f"{TILE}x{TILE} tiles dealt over {world} GPUs, "
                                       f"{sh.weights or [1] * world} of every {sum(sh.weights or [1] * world)} (the gathering rank renders less), RCCL gather to rank 0"},
         }
+        # what N > 1 lines are to be compared with: one GPU on the route they time (picture, groups, assemble)
+        out["scaling_base_ms_per_step"] = base_ms
+        out["scaling_base_note"] = ("one GPU, the N > 1 route: k_render direct lighting + shadow term (same rays), groups of "
+                                    f"{GROUP} frames, RGB8, assembled to RGBA8, no collective")
+        if multi and base_ms:
+            out["speedup_vs_scaling_base"] = base_ms / ms_per_step
+        out["timed_kernel"] = ("k_trace_primary<shadow>: rt_hit records" if not multi else
+                               "k_render<single bounce, shadow term>: RGB8 picture, rt_gather_frames (RCCL), rt_assemble_frames")
         if not multi:
             abytes = algorithmic_bytes(stats)
             mbytes = moved_bytes(moved, WIDTH * HEIGHT)

@@ -42,6 +42,13 @@ extern "C" {
                                     out_primary: *mut RtHit, out_shadow: *mut RtHit) -> c_int;
     pub fn rt_trace_rays(ctx: *mut RtCtx, camera: *const c_void, origins: *const f32, dirs: *const f32, n: u32,
                          out: *mut RtHit, any_hit: c_int) -> c_int;
+    /// Several GPUs, one process each (include/rt_mi355.h, "several GPUs"): RCCL scene broadcast and framebuffer gather.
+    pub fn rt_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn rt_comm_init(ctx: *mut RtCtx, id: *const u8, rank: c_int, n_ranks: c_int) -> c_int;
+    pub fn rt_comm_info(ctx: *mut RtCtx, rank: *mut c_int, n_ranks: *mut c_int) -> c_int;
+    pub fn rt_comm_destroy(ctx: *mut RtCtx) -> c_int;
+    pub fn rt_broadcast_scene(ctx: *mut RtCtx, root: c_int, boxes: *const c_void, nb: u32, tris: *const c_void, nt: u32) -> c_int;
+    pub fn rt_gather_frames(ctx: *mut RtCtx, root: c_int, local: *const c_void, bytes: usize, gathered: *mut c_void) -> c_int;
     pub fn rt_set_stream(ctx: *mut RtCtx, hip_stream: *mut c_void) -> c_int;
     pub fn rt_set_materials(ctx: *mut RtCtx, materials: *const c_void, n: u32) -> c_int;
     pub fn rt_get_trace_refs(ctx: *mut RtCtx, n_trace_refs: *mut u32) -> c_int;

@@ -39,7 +39,8 @@ typedef enum rt_status {
     RT_ERR_NO_DEVICE = -2, /* no usable GPU / HIP runtime error at create */
     RT_ERR_HIP = -3,       /* HIP runtime error during a call */
     RT_ERR_STATE = -4,     /* scene or grid missing */
-    RT_ERR_LIMIT = -5      /* a size exceeds a documented limit */
+    RT_ERR_LIMIT = -5,     /* a size exceeds a documented limit */
+    RT_ERR_COMM = -6       /* RCCL missing or an RCCL call failed */
 } rt_status;
 
 /* Object id reported on a miss. */
@@ -149,6 +150,10 @@ void rt_camera_to_uniform(const float position[3], float yaw, float pitch, float
  * boxes/tris: host pointers, nb/nt may be 0. Invalidates any grid. */
 int rt_set_scene(rt_ctx* ctx, const BoxData* boxes, uint32_t nb, const TriangleData* tris, uint32_t nt);
 
+/* Number of boxes and triangles of the current scene (a rank that received its scene through rt_broadcast_scene
+ * learns the sizes here). */
+int rt_get_scene(rt_ctx* ctx, uint32_t* nb, uint32_t* nt);
+
 /* Replaces the "Fine Cells" upload (src/renderer.rs:99,113-117) for a caller that
  * already ran HierarchicalGrid::to_gpu_buffers (src/grid.rs:301-358): fine_cells is
  * the dense FineCellData[n_cells] array (host). Converted to a compact cell list. */
@@ -234,6 +239,33 @@ int rt_assemble_tiles(rt_ctx* ctx, const rt_hit* gathered, uint32_t width, uint3
  * (raytracer_unified.wgsl:695-709), geometry fields only (hit_color is zero). */
 int rt_debug_pixel(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
                    uint32_t px, uint32_t py, RayDebugInfo* info);
+
+/* ---- several GPUs: one process per GPU, RCCL over xGMI ----------------------------------- */
+
+/* None of these has a counterpart in the reference, which renders on one GPU (src/renderer.rs:857-868 dispatches the
+ * whole frame). A frame shards by image tile (rt_shard); the scene is replicated once per scene load and every frame's
+ * tiles are gathered on one rank. RCCL is bound at run time (dlopen of the copy already in the process, else the
+ * system's); without it these calls fail with RT_ERR_COMM and everything else works.
+ *
+ * rt_comm_unique_id: on ONE rank; the caller hands the RT_COMM_ID_BYTES bytes to the other ranks by any means it has
+ *   (a file, a socket, MPI, an environment variable).
+ * rt_comm_init: collective over all n_ranks contexts (one per process, each on its own GPU): ncclCommInitRank.
+ * rt_broadcast_scene: collective. Rank `root` passes its host arrays as for rt_set_scene (the other ranks' array
+ *   arguments are ignored); afterwards every rank holds that scene exactly as if it had called rt_set_scene itself:
+ *   the bytes cross PCIe once, on the root, and go from GPU to GPU straight into the scene buffers. Each rank then
+ *   bins its own grid (rt_build_grid is deterministic, so the grids are identical without being shipped).
+ * rt_gather_frames: collective, queued on the context's stream like a launch (it does not block the host). Every rank
+ *   passes `bytes` bytes of device memory (its packed tiles from rt_trace_primary / rt_render[_frames] with its
+ *   shard); on `root`, gathered[r * bytes ...] receives rank r's block (gathered is ignored elsewhere). N-1 grouped
+ *   point-to-point transfers, one per link into the root. rt_assemble_* then scatters the tiles into frames.
+ *   Calls on one context must be issued in the same order on every rank. */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(uint8_t* id /* RT_COMM_ID_BYTES */);
+int rt_comm_init(rt_ctx* ctx, const uint8_t* id /* RT_COMM_ID_BYTES */, int rank, int n_ranks);
+int rt_comm_info(rt_ctx* ctx, int* rank, int* n_ranks);
+int rt_comm_destroy(rt_ctx* ctx); /* also done by rt_destroy */
+int rt_broadcast_scene(rt_ctx* ctx, int root, const BoxData* boxes, uint32_t nb, const TriangleData* tris, uint32_t nt);
+int rt_gather_frames(rt_ctx* ctx, int root, const void* local, size_t bytes, void* gathered);
 
 /* ---- bounding volume hierarchy ----------------------------------------------------------- */
 

@@ -29,7 +29,8 @@ assert TRIANGLE_DTYPE.itemsize == 80 and BOX_DTYPE.itemsize == 96 and HIT_DTYPE.
 assert MATERIAL_DTYPE.itemsize == 64
 
 RT_MISS = 0xFFFFFFFF
-RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_STATE, RT_ERR_LIMIT = 0, -1, -2, -3, -4, -5
+RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_STATE, RT_ERR_LIMIT, RT_ERR_COMM = 0, -1, -2, -3, -4, -5, -6
+RT_COMM_ID_BYTES = 128
 RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES = 0, 1
 RT_NOALLOC_MAX_BOXES = 8192
 
@@ -119,6 +120,7 @@ PROTOTYPES = {
     "rt_camera_to_uniform": (None, [_FP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I,
                                     C.POINTER(CameraUniform)]),
     "rt_set_scene": (_I, [_VP, _VP, _U32, _VP, _U32]),
+    "rt_get_scene": (_I, [_VP, C.POINTER(_U32), C.POINTER(_U32)]),
     "rt_set_grid_dense": (_I, [_VP, C.POINTER(GridMetadata), _VP, C.c_size_t]),
     "rt_set_grid_dense_tri": (_I, [_VP, C.POINTER(GridMetadata), _VP, C.c_size_t]),
     "rt_set_grid_csr": (_I, [_VP, C.POINTER(GridMetadata), _VP, _VP]),
@@ -130,6 +132,12 @@ PROTOTYPES = {
     "rt_trace_primary_noalloc": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, C.POINTER(RtShard), _VP, _VP]),
     "rt_trace_rays": (_I, [_VP, C.POINTER(CameraUniform), _VP, _VP, _U32, _VP, _I]),
     "rt_assemble_tiles": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, C.c_size_t, _VP]),
+    "rt_comm_unique_id": (_I, [_VP]),
+    "rt_comm_init": (_I, [_VP, _VP, _I, _I]),
+    "rt_comm_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
+    "rt_comm_destroy": (_I, [_VP]),
+    "rt_broadcast_scene": (_I, [_VP, _I, _VP, _U32, _VP, _U32]),
+    "rt_gather_frames": (_I, [_VP, _I, _VP, C.c_size_t, _VP]),
     "rt_build_bvh": (_I, [_VP]),
     "rt_get_bvh_stats": (_I, [_VP, C.POINTER(RtBvhStats)]),
     "rt_trace_rays_bvh": (_I, [_VP, _VP, _VP, _U32, _VP]),

@@ -560,6 +560,46 @@ int emit_cells(rt_ctx* c) {
     return RT_OK;
 }
 
+// A new scene in three steps, shared by rt_set_scene (host arrays) and rt_broadcast_scene (arrays that arrive from
+// another GPU): begin_scene waits for readers of the old scene and forgets what depended on it; reserve_scene sizes the
+// buffers - boxes as they are, triangles as 80-byte wire records in `misc`; finish_scene unpacks the triangle records
+// on the device (36-byte vertex records kept: the rest - uv, material - is not geometry) and waits.
+int begin_scene(rt_ctx* c) {
+    if (int r = scene_barrier(c)) return r;
+    c->has_grid = false;
+    c->dup_state = -1;
+    c->has_skin = false;  // a skin belongs to the triangles it was set for
+    c->has_bvh = false;
+    return RT_OK;
+}
+
+int reserve_scene(rt_ctx* c, uint32_t nb, uint32_t nt) {
+    RT_HIP(c, c->boxes.reserve((size_t)nb * sizeof(BoxData) + 16));
+    RT_HIP(c, c->tri_v.reserve((size_t)nt * 9 * sizeof(float) + 16));
+    if (nt) {
+        RT_HIP(c, c->misc.reserve((size_t)nt * sizeof(TriangleData)));
+        RT_HIP(c, c->tri_mat.reserve((size_t)nt * sizeof(uint32_t)));
+        RT_HIP(c, c->tri_uv.reserve((size_t)nt * 6 * sizeof(float)));
+        RT_HIP(c, c->tri_n.reserve((size_t)nt * sizeof(float4)));
+    }
+    return RT_OK;
+}
+
+int finish_scene(rt_ctx* c, uint32_t nb, uint32_t nt) {
+    c->nb = nb;
+    c->nt = nt;
+    if (nt) {
+        hipLaunchKernelGGL(k_tri_unpack, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->misc.as<TriangleData>(), nt,
+                           c->tri_v.as<float>(), c->tri_mat.as<uint32_t>(), c->tri_uv.as<float>());
+        RT_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL(k_tri_normals, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->tri_v.as<float>(), 0u, nt,
+                           c->tri_n.as<float4>());
+        RT_HIP(c, hipGetLastError());
+    }
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
 }  // namespace rt
 
 // ================================================================== lifecycle
@@ -642,6 +682,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)rt_comm_destroy(c);
     DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->tri_n,     &c->tri_mat,   &c->materials, &c->skin_pos, &c->skin_joints,
                       &c->skin_weights, &c->skin_tri, &c->skin_mats, &c->bvh_nodes, &c->bvh_leaf_first, &c->bvh_prims, &c->bvh_recs,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
@@ -743,31 +784,17 @@ extern "C" int rt_set_scene(rt_ctx* c, const BoxData* boxes, uint32_t nb, const 
     if (int r = use(c)) return r;
     if ((nb && !boxes) || (nt && !tris)) return fail(c, RT_ERR_INVALID, "rt_set_scene: NULL array with non-zero count");
     if ((uint64_t)nb + nt >= 0xFFFFFFF0ull) return fail(c, RT_ERR_LIMIT, "rt_set_scene: more than 2^32-16 objects");
-    if (int r = scene_barrier(c)) return r;
-    c->has_grid = false;
-    c->dup_state = -1;
-    c->has_skin = false;  // a skin belongs to the triangles it was set for
-    c->has_bvh = false;
-    c->nb = nb;
-    c->nt = nt;
-    RT_HIP(c, c->boxes.reserve((size_t)nb * sizeof(BoxData) + 16));
-    RT_HIP(c, c->tri_v.reserve((size_t)nt * 9 * sizeof(float) + 16));
+    if (int r = begin_scene(c)) return r;
+    if (int r = reserve_scene(c, nb, nt)) return r;
     if (nb) RT_HIP(c, hipMemcpyAsync(c->boxes.p, boxes, (size_t)nb * sizeof(BoxData), hipMemcpyHostToDevice, c->stream));
-    if (nt) {
-        // 80-byte records in, 36-byte vertex records kept: the rest (uv, material) is not geometry
-        RT_HIP(c, c->misc.reserve((size_t)nt * sizeof(TriangleData)));
-        RT_HIP(c, hipMemcpyAsync(c->misc.p, tris, (size_t)nt * sizeof(TriangleData), hipMemcpyHostToDevice, c->stream));
-        RT_HIP(c, c->tri_mat.reserve((size_t)nt * sizeof(uint32_t)));
-        RT_HIP(c, c->tri_uv.reserve((size_t)nt * 6 * sizeof(float)));
-        hipLaunchKernelGGL(k_tri_unpack, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->misc.as<TriangleData>(), nt,
-                           c->tri_v.as<float>(), c->tri_mat.as<uint32_t>(), c->tri_uv.as<float>());
-        RT_HIP(c, hipGetLastError());
-        RT_HIP(c, c->tri_n.reserve((size_t)nt * sizeof(float4)));
-        hipLaunchKernelGGL(k_tri_normals, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->tri_v.as<float>(), 0u, nt,
-                           c->tri_n.as<float4>());
-        RT_HIP(c, hipGetLastError());
-    }
-    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (nt) RT_HIP(c, hipMemcpyAsync(c->misc.p, tris, (size_t)nt * sizeof(TriangleData), hipMemcpyHostToDevice, c->stream));
+    return finish_scene(c, nb, nt);
+}
+
+extern "C" int rt_get_scene(rt_ctx* c, uint32_t* nb, uint32_t* nt) {
+    if (int r = use(c)) return r;
+    if (nb) *nb = c->nb;
+    if (nt) *nt = c->nt;
     return RT_OK;
 }
 

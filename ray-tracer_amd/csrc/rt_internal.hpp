@@ -121,6 +121,9 @@ struct rt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // Frames in flight on several streams (rt_set_stream): see the rules at rt_set_stream in rt_api.hip.
     hipEvent_t ev_order = nullptr;
+    // multi-GPU (rt_comm_init): an ncclComm_t, kept untyped so that only rt_comm.hip needs RCCL's header
+    void* comm = nullptr;
+    int comm_rank = 0, comm_size = 0;
     bool scratch_busy = false;        // work using the context's per-frame scratch is queued on the current stream
     bool other_streams_busy = false;  // a stream used earlier may still hold trace work that reads the scene
 };
@@ -157,6 +160,10 @@ inline bool is_device_ptr(const void* p) {
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// implemented in rt_api.hip: the steps of installing a new scene (see there)
+int begin_scene(rt_ctx* c);
+int reserve_scene(rt_ctx* c, uint32_t nb, uint32_t nt);
+int finish_scene(rt_ctx* c, uint32_t nb, uint32_t nt);
 // implemented in rt_build.hip
 int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode);
 // implemented in rt_api.hip: t_cell_start on device -> bordered cell records; reserves the reference records

@@ -130,6 +130,7 @@ class TraceCore:
         if rc != 0:
             raise RtError(rc, self._L.rt_create_error().decode())
         self.device_id = device_id
+        self.comm_rank, self.comm_size = 0, 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -203,6 +204,40 @@ class TraceCore:
         else:
             n = xyz9.numel() // 9
         self._ck(self._L.rt_update_vertices(self._h, _ptr(xyz9), first, n if count is None else count))
+
+    # ---- several GPUs (RCCL through the C ABI)
+    @staticmethod
+    def comm_unique_id():
+        """RT_COMM_ID_BYTES bytes made on one rank; hand them to the others, then every rank calls comm_init."""
+        buf = (C.c_uint8 * _lib.RT_COMM_ID_BYTES)()
+        rc = _lib.load().rt_comm_unique_id(buf)
+        if rc != 0:
+            raise RtError(rc, "rt_comm_unique_id failed (RCCL missing?)")
+        return bytes(buf)
+
+    def comm_init(self, comm_id, rank, n_ranks):
+        buf = (C.c_uint8 * _lib.RT_COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        self._ck(self._L.rt_comm_init(self._h, buf, rank, n_ranks))
+        self.comm_rank, self.comm_size = rank, n_ranks
+
+    def comm_destroy(self):
+        self._ck(self._L.rt_comm_destroy(self._h))
+        self.comm_size = 0
+
+    def broadcast_scene(self, root, boxes=None, tris=None):
+        """Collective: rank `root`'s arrays become every rank's scene (as set_scene would). Returns (nb, nt)."""
+        boxes = np.ascontiguousarray(boxes if boxes is not None else np.zeros(0, BOX_DTYPE), BOX_DTYPE)
+        tris = np.ascontiguousarray(tris if tris is not None else np.zeros(0, TRIANGLE_DTYPE), TRIANGLE_DTYPE)
+        self._ck(self._L.rt_broadcast_scene(self._h, root, _ptr(boxes), len(boxes), _ptr(tris), len(tris)))
+        nb, nt = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.rt_get_scene(self._h, C.byref(nb), C.byref(nt)))
+        self.nb, self.nt = nb.value, nt.value
+        return self.nb, self.nt
+
+    def gather_frames(self, root, local, n_bytes, gathered=None):
+        """Collective, asynchronous on the context's stream: every rank's `n_bytes` device bytes land in
+        gathered[r * n_bytes ...] on rank `root`."""
+        self._ck(self._L.rt_gather_frames(self._h, root, _ptr(local), n_bytes, _ptr(gathered)))
 
     # ---- tracing
     # ---- bounding volume hierarchy

@@ -67,6 +67,29 @@ def gatherer_weights(world, resolution=64, lag=3):
     return [k - lag] + [k] * (world - 1)
 
 
+def init_comm(core, rank=None, world=None, src=0):
+    """Gives `core` (a TraceCore) an RCCL communicator over all ranks of the torch.distributed job, through the C ABI
+    (rt_comm_unique_id on rank `src`, the 128 bytes handed round with the job's own process group, rt_comm_init on
+    every rank). From then on FrameSharder gathers with rt_gather_frames and `replicate_scene` broadcasts with
+    rt_broadcast_scene: RCCL on the trace core's own stream, device to device, no torch tensors in the data path."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    box = [core.comm_unique_id() if rank == src else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=src)
+    core.comm_init(box[0], rank, world)
+
+
+def replicate_scene(core, boxes, tris, src=0):
+    """Rank `src`'s scene arrays become every rank's scene: rt_broadcast_scene when the core has a communicator
+    (init_comm), else the torch.distributed fall-back below followed by set_scene."""
+    if getattr(core, "comm_size", 0):
+        core.broadcast_scene(src, boxes, tris)
+        return
+    b, t = broadcast_scene(boxes, tris, torch.device("cuda", core.device_id))
+    core.set_scene(b, t)
+
+
 def broadcast_scene(boxes, tris, device, src=0):
     """Replicates rank `src`'s scene arrays (numpy structured arrays in the wire format; ignored on
     the other ranks) and returns (boxes, tris) as numpy arrays on every rank."""
@@ -148,7 +171,7 @@ class FrameSharder:
                  valid until that many further frames have been started."""
 
     def __init__(self, core, width, height, tile_w=64, tile_h=64, rank=None, world=None, device="cuda", shadow=True,
-                 mode="hits", frames_in_flight=1, max_bounces=8, collective=None, weights=None):
+                 mode="hits", frames_in_flight=1, max_bounces=8, collective=None, weights=None, host_gather=False):
         if mode not in ("hits", "rgba"):
             raise ValueError("mode must be 'hits' or 'rgba'")
         self.core, self.width, self.height, self.tile_w, self.tile_h = core, width, height, tile_w, tile_h
@@ -158,6 +181,16 @@ class FrameSharder:
         # the gather is skipped for a lone rank unless asked for (a one-rank process group exercises the backend)
         self.collective = self.world > 1 if collective is None else bool(collective)
         self.device = device
+        # a core with a communicator of its own (init_comm) gathers through the C ABI; the CPU tests' stand-in cores
+        # and cores without one go through torch.distributed
+        # host_gather: the torch.distributed gather of frame groups runs on host copies (device -> host, gloo on CPU
+        # tensors, host -> device), synchronously. Only for rehearsing several ranks on ONE GPU, where RCCL is not
+        # available and gloo's own handling of device tensors (private streams, pinned staging, host-blocking waits
+        # in every process that shares the GPU) stalled for seconds to minutes.
+        self.host_gather = bool(host_gather)
+        self.native_comm = bool(getattr(core, "comm_size", 0))
+        if self.native_comm and (core.comm_size != self.world or core.comm_rank != self.rank):
+            raise ValueError("the core's communicator and the sharder disagree on rank / world size")
         # weights[r]: tiles rank r owns out of every sum(weights) ("rgba" mode), dealt as owner_table says. Rank 0 also
         # gathers and assembles, so it is given less to render than the others; None = one tile each.
         self.weights = None if weights is None else [int(k) for k in weights]
@@ -245,7 +278,20 @@ class FrameSharder:
             self.core.render_frames(cams[j:j + 16], self.width, self.height, shard=self.shard, max_bounces=self.max_bounces,
                                     shadows=self.shadow, out=slot.local[j:min(g, j + 16)], rgb8=rgb8,
                                     frame_stride=self.per_rank)
-        if self.collective:
+        if self.collective and self.native_comm:
+            # rt_gather_frames on the trace core's stream: whole per-rank blocks (unused frames of a short group
+            # travel too: a group is short only at the end of a path)
+            self.core.gather_frames(0, slot.local, slot.local.numel(), slot.packed)
+        elif self.collective and self.host_gather:
+            if slot.stream is not None:
+                slot.stream.synchronize()
+            mine = slot.local[:g].cpu()
+            parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(mine, parts, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    slot.packed[r, :g].copy_(parts[r])
+        elif self.collective:
             if g not in slot.views:  # tensor views are not free to make: once per group length
                 slot.views[g] = (slot.local[:g], [slot.packed[r, :g] for r in range(self.world)] if self.rank == 0 else None)
             mine, parts = slot.views[g]
@@ -259,7 +305,9 @@ class FrameSharder:
 
     def _trace(self, cam, slot):
         self._local(cam, slot)
-        if self.collective:
+        if self.collective and self.native_comm:
+            self.core.gather_frames(0, slot.local, slot.local.numel() * slot.local.element_size(), slot.packed)
+        elif self.collective:
             dist.gather(slot.local, slot.gathered, dst=0)
         if self.rank != 0:
             return None

@@ -175,6 +175,14 @@ typedef enum rt_grid_mode {
  * cell_size <= 0 and max_per_cell == 0 select the context's params. */
 int rt_build_grid(rt_ctx* ctx, float cell_size, uint32_t max_per_cell, int mode);
 
+/* How the current grid was made: 0 = rt_build_grid's general path (sizes read back by the host between passes,
+ * duplicate search, any scene), 1 = its rebuild path for scenes of up to 65 536 objects whose grid has been built
+ * before with the same mode, cell size and cap (rt_update_vertices / rt_skin_vertices + rt_build_grid, the animated
+ * case): every size stays on the device, launches cover the capacity the previous build left behind, one 64-byte
+ * read-back at the end; a frame that does not fit falls back to 0 by itself. -1 = the caller supplied the grid.
+ * Same cell lists either way. No reference counterpart. */
+int rt_get_build_path(rt_ctx* ctx, int* path);
+
 /* Metadata and sizes of the current grid. */
 int rt_get_grid(rt_ctx* ctx, GridMetadata* meta, uint32_t* n_cells, uint32_t* n_refs);
 /* Number of reference records the trace kernels walk for the current grid: n_refs of rt_get_grid minus the

@@ -570,6 +570,7 @@ int begin_scene(rt_ctx* c) {
     c->dup_state = -1;
     c->has_skin = false;  // a skin belongs to the triangles it was set for
     c->has_bvh = false;
+    c->fast_ready = false;
     return RT_OK;
 }
 
@@ -688,7 +689,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
                       &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->b_obj_n, &c->b_obj_off, &c->b_obj_sum, &c->out_p,     &c->out_s,
                       &c->in_o,      &c->in_d,      &c->stats,      &c->misc,      &c->tri_uv,    &c->texels,    &c->tc_start,  &c->tc_indices, &c->tc_pos, &c->dd_keys, &c->dd_keys2,
-                      &c->dd_vals, &c->dd_vals2, &c->dd_flag, &c->dd_head, &c->dd_dup, &c->ref_cell, &c->tc_ref_cell};
+                      &c->dd_vals, &c->dd_vals2, &c->dd_flag, &c->dd_head, &c->dd_dup, &c->ref_cell, &c->tc_ref_cell, &c->fast_meta};
     for (DevBuf* b : bufs) b->release();
     for (rt_table* t : c->tables) {
         t->buf.release();
@@ -890,6 +891,14 @@ extern "C" int rt_get_grid(rt_ctx* c, GridMetadata* meta, uint32_t* n_cells, uin
     if (meta) *meta = c->meta;
     if (n_cells) *n_cells = c->n_cells;
     if (n_refs) *n_refs = c->n_refs;
+    return RT_OK;
+}
+
+extern "C" int rt_get_build_path(rt_ctx* c, int* path) {
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_get_build_path: no grid");
+    if (!path) return fail(c, RT_ERR_INVALID, "rt_get_build_path: NULL argument");
+    *path = c->grid_built ? (c->last_build_fast ? 1 : 0) : -1;
     return RT_OK;
 }
 

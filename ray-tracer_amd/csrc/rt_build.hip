@@ -10,6 +10,8 @@
 // cap + compaction -> 48-byte reference records -> re-test masks.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -192,13 +194,11 @@ __global__ __launch_bounds__(256) void k_bin(BinGrid g, const BoxData* __restric
 // cells, so "listed one step back" is the same as "already tested". Cells whose lists may have been cut by the
 // per-cell cap never vouch for their neighbours (their bits stay 0), which keeps the skip exact. full_start: the
 // reference's lists (whether a cell was cut by the cap is a property of those, not of lists with copies left out).
-__global__ void k_emit_records(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
-                               const uint32_t* __restrict__ indices, const uint32_t* __restrict__ ref_cell,
-                               const uint32_t* __restrict__ full_start, uint32_t n_refs, uint32_t cap,
-                               const uint32_t* __restrict__ tri_mat, const float4* __restrict__ materials, uint32_t n_materials,
-                               float4* __restrict__ refs) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_refs) return;
+__device__ inline void emit_record(const BinGrid& g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                                   const uint32_t* __restrict__ indices, const uint32_t* __restrict__ ref_cell,
+                                   const uint32_t* __restrict__ full_start, uint32_t cap, const uint32_t* __restrict__ tri_mat,
+                                   const float4* __restrict__ materials, uint32_t n_materials, float4* __restrict__ refs,
+                                   uint32_t r) {
     const uint32_t id = indices[r];
     uint32_t word = id, mat_word = 0, mask = 0;
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
@@ -256,6 +256,16 @@ __global__ void k_emit_records(BinGrid g, const BoxData* __restrict__ boxes, con
     refs[3 * (size_t)r] = q0;
     refs[3 * (size_t)r + 1] = q1;
     refs[3 * (size_t)r + 2] = q2;
+}
+
+__global__ void k_emit_records(BinGrid g, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                               const uint32_t* __restrict__ indices, const uint32_t* __restrict__ ref_cell,
+                               const uint32_t* __restrict__ full_start, uint32_t n_refs, uint32_t cap,
+                               const uint32_t* __restrict__ tri_mat, const float4* __restrict__ materials, uint32_t n_materials,
+                               float4* __restrict__ refs) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_refs) return;
+    emit_record(g, boxes, tri_v, indices, ref_cell, full_start, cap, tri_mat, materials, n_materials, refs, r);
 }
 
 __global__ void k_clamp_counts(const uint32_t* __restrict__ counts, uint32_t n_cells, uint32_t cap,
@@ -357,6 +367,288 @@ __global__ void k_compact_starts(const uint32_t* __restrict__ cell_start, const 
     if (c <= n_cells) out[c] = pos[cell_start[c]];
 }
 
+
+// ---- rebuild without host round trips ----------------------------------------------------------------------
+// The animated path rebuilds the grid of a small scene every frame (rt_update_vertices / rt_skin_vertices, then
+// rt_build_grid). The general path above asks the host for sizes four times per build (bounds -> dimensions, pair
+// count, reference count, duplicates) and goes through about thirty launches; for a scene of a few thousand triangles
+// those waits and launch gaps cost more than the kernels. This path keeps every size on the device (FastMeta), launches
+// over the CAPACITY of the buffers the last build left behind, and reads 64 bytes back once, at the end. Whatever does
+// not fit - more cells, pairs or references than the buffers hold, a cell list too long for the quadratic ranking
+// below - raises `overflow`, and the host then runs the general path, which is exact for everything. The cell lists
+// are the same either way: same bounds (min / max are order-independent), same dimensions (the same correctly rounded
+// f32 operations), ids ascending inside a cell, the lowest `cap` ids kept.
+struct FastMeta {
+    float bmin[3], bmax[3];
+    uint32_t gx, gy, gz, n_cells;
+    uint32_t n_pairs, n_refs, overflow, max_count;
+    uint32_t pad[2];
+};
+static_assert(sizeof(FastMeta) == 64, "FastMeta is read back as 64 bytes");
+
+struct FastCaps {
+    uint32_t cells;     // entries of the per-cell arrays minus one
+    uint32_t bordered;  // records of the bordered cell array
+    uint32_t pairs;     // entries of the per-pair arrays
+    uint32_t refs;      // reference records minus the padding record
+};
+
+constexpr uint32_t FAST_MAX_OBJECTS = 65536;  // one workgroup scans the per-object pair counts
+constexpr uint32_t FAST_MAX_LIST = 1024;      // longest cell list the ranking kernel accepts
+
+__device__ inline BinGrid fast_grid(const FastMeta& m, float cell, uint32_t nb, uint32_t nt, int tri_mode) {
+    BinGrid g;
+    g.bmin[0] = m.bmin[0], g.bmin[1] = m.bmin[1], g.bmin[2] = m.bmin[2];
+    g.cell = cell;
+    g.gx = m.gx, g.gy = m.gy, g.gz = m.gz;
+    g.nb = nb, g.nt = nt;
+    g.tri_mode = tri_mode;
+    return g;
+}
+
+// One workgroup: bounds of all objects, padded; dimensions; capacity checks.
+__global__ __launch_bounds__(1024) void kf_bounds_dims(const BoxData* __restrict__ boxes, const float* __restrict__ tri_v, uint32_t nb,
+                                                      uint32_t total, float cell_size, int tri_mode, FastCaps caps,
+                                                      FastMeta* __restrict__ meta) {
+    __shared__ float red[6][1024];
+    V3 mn = v3(INFINITY, INFINITY, INFINITY), mx = v3(-INFINITY, -INFINITY, -INFINITY);
+    for (uint32_t id = threadIdx.x; id < total; id += 1024) {
+        V3 a, b;
+        object_bounds(boxes, tri_v, nb, id, a, b);
+        mn = vmin(mn, a);
+        mx = vmax(mx, b);
+    }
+    const uint32_t t = threadIdx.x;
+    red[0][t] = mn.x, red[1][t] = mn.y, red[2][t] = mn.z;
+    red[3][t] = mx.x, red[4][t] = mx.y, red[5][t] = mx.z;
+    __syncthreads();
+    for (uint32_t s = 512; s > 0; s >>= 1) {
+        if (t < s) {
+            for (int k = 0; k < 3; ++k) red[k][t] = fminf(red[k][t], red[k][t + s]);
+            for (int k = 3; k < 6; ++k) red[k][t] = fmaxf(red[k][t], red[k][t + s]);
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    FastMeta m;
+    memset(&m, 0, sizeof(m));
+    const V3 bmin = v3(red[0][0], red[1][0], red[2][0]) - v3(1.0f, 1.0f, 1.0f);  // src/grid.rs:130-134
+    const V3 bmax = v3(red[3][0], red[4][0], red[5][0]) + v3(1.0f, 1.0f, 1.0f);
+    m.bmin[0] = bmin.x, m.bmin[1] = bmin.y, m.bmin[2] = bmin.z;
+    m.bmax[0] = bmax.x, m.bmax[1] = bmax.y, m.bmax[2] = bmax.z;
+    const V3 e = bmax - bmin;
+    const float ext[3] = {e.x, e.y, e.z};
+    const float div = tri_mode ? fmaxf(cell_size, RT_TRI_MIN_CELL_SIZE) : cell_size;
+    unsigned long long dims[3];
+    for (int k = 0; k < 3; ++k) {  // src/grid.rs:9-16; src/grid_triangles.rs:126-139
+        const float q = ceilf(ext[k] / div);
+        unsigned long long v = !(q > 0.0f) ? 0ull : (q >= 4294967296.0f ? 0xFFFFFFFFull : (unsigned long long)q);
+        if (tri_mode) v = v < 1 ? 1 : (v > RT_TRI_MAX_GRID_DIM ? RT_TRI_MAX_GRID_DIM : v);
+        dims[k] = v;
+    }
+    const bool bad = dims[0] == 0 || dims[1] == 0 || dims[2] == 0 || dims[0] > 0xFFFFull * 16 || dims[1] > 0xFFFFull * 16 ||
+                     dims[2] > 0xFFFFull * 16;
+    unsigned long long cells = bad ? 0 : dims[0] * dims[1] * dims[2];
+    unsigned long long bordered = bad ? 0 : (dims[0] + 2) * (dims[1] + 2) * (dims[2] + 2);
+    if (bad || cells > caps.cells || bordered > caps.bordered) {
+        m.overflow = 1;
+        cells = 0;
+    }
+    m.gx = (uint32_t)dims[0], m.gy = (uint32_t)dims[1], m.gz = (uint32_t)dims[2];
+    m.n_cells = (uint32_t)cells;
+    *meta = m;
+}
+
+__global__ __launch_bounds__(256) void kf_obj_pairs(const FastMeta* __restrict__ meta, float cell, uint32_t nb, uint32_t nt, int tri_mode,
+                                                    const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                                                    uint32_t* __restrict__ obj_n) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = nb + nt;
+    if (id > total) return;
+    uint32_t n = 0;
+    if (id < total && !meta->overflow) {
+        const BinGrid g = fast_grid(*meta, cell, nb, nt, tri_mode);
+        V3 mn, mx;
+        object_bounds(boxes, tri_v, nb, id, mn, mx);
+        const Range3 r = cell_range(g, mn, mx);
+        const unsigned long long v = (unsigned long long)(r.hi[0] - r.lo[0] + 1) * (unsigned long long)(r.hi[1] - r.lo[1] + 1) *
+                                     (unsigned long long)(r.hi[2] - r.lo[2] + 1);
+        n = r.lo[0] > r.hi[0] ? 0u : (v > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)v);
+    }
+    obj_n[id] = n;
+}
+
+// Exclusive scan of n + 1 words by one workgroup (64-bit running sums: an overflowing total must be seen, not wrapped).
+// in[n] is the closing element (its value is ignored, out[n] = total). Returns the total in every thread.
+__device__ inline unsigned long long block_scan_1024(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
+                                                     unsigned long long* sh /* 1024 */) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = (n + 1023) / 1024;
+    const uint32_t a = min(t * chunk, n), b = min(a + chunk, n);
+    unsigned long long sum = 0;
+    for (uint32_t k = a; k < b; ++k) sum += in[k];
+    sh[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive scan of the 1024 partial sums
+        const unsigned long long v = t >= off ? sh[t - off] : 0ull;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    const unsigned long long total = sh[1023];
+    unsigned long long run = sh[t] - sum;
+    for (uint32_t k = a; k < b; ++k) {
+        const uint32_t v = in[k];
+        out[k] = (uint32_t)run;
+        run += v;
+    }
+    if (t == 0) out[n] = (uint32_t)total;
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void kf_scan_objs(const uint32_t* __restrict__ obj_n, uint32_t* __restrict__ obj_off, uint32_t total,
+                                                    FastCaps caps, FastMeta* __restrict__ meta) {
+    __shared__ unsigned long long sh[1024];
+    const unsigned long long pairs = block_scan_1024(obj_n, obj_off, total, sh);
+    if (threadIdx.x == 0) {
+        if (pairs > caps.pairs) {
+            meta->overflow = 1;
+            meta->n_pairs = 0;
+        } else {
+            meta->n_pairs = (uint32_t)pairs;
+        }
+    }
+}
+
+// One lane per (object, cell) pair: the pair's cell, id and its slot in the cell's list (arbitrary order).
+__global__ __launch_bounds__(256) void kf_bin_count(const FastMeta* __restrict__ meta, float cell, uint32_t nb, uint32_t nt, int tri_mode,
+                                                    const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                                                    const uint32_t* __restrict__ obj_off, uint32_t* __restrict__ counts,
+                                                    uint32_t* __restrict__ slots, uint32_t* __restrict__ pair_cell,
+                                                    uint32_t* __restrict__ pair_id) {
+    const uint32_t n_pairs = meta->n_pairs;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n_pairs) return;  // whole workgroup
+    __shared__ uint32_t window[2];
+    if (threadIdx.x < 2) {
+        const uint32_t last = n_pairs - 1;
+        const uint32_t q = threadIdx.x == 0 ? blockIdx.x * blockDim.x : min(blockIdx.x * blockDim.x + blockDim.x - 1, last);
+        uint32_t lo = 0, hi = nb + nt;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (obj_off[mid] <= q) lo = mid; else hi = mid;
+        }
+        window[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    if (p >= n_pairs) return;
+    uint32_t lo = window[0], hi = window[1] + 1;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (obj_off[mid] <= p) lo = mid; else hi = mid;
+    }
+    const uint32_t id = lo;
+    const BinGrid g = fast_grid(*meta, cell, nb, nt, tri_mode);
+    V3 mn, mx;
+    object_bounds(boxes, tri_v, nb, id, mn, mx);
+    const Range3 r = cell_range(g, mn, mx);
+    const uint32_t nx = (uint32_t)(r.hi[0] - r.lo[0] + 1), ny = (uint32_t)(r.hi[1] - r.lo[1] + 1);
+    const uint32_t j = p - obj_off[id];
+    const uint32_t x = (uint32_t)r.lo[0] + j % nx, y = (uint32_t)r.lo[1] + (j / nx) % ny, z = (uint32_t)r.lo[2] + j / (nx * ny);
+    const uint32_t c = x + y * g.gx + z * g.gx * g.gy;
+    slots[p] = atomicAdd(&counts[c], 1u);
+    pair_cell[p] = c;
+    pair_id[p] = id;
+}
+
+// One workgroup: where every cell's unsorted ids go (scan of the counts) and where its kept ids go (scan of the counts
+// cut to the cap); the reference count; the longest list.
+__global__ __launch_bounds__(1024) void kf_scan_cells(const uint32_t* __restrict__ counts, uint32_t* __restrict__ clamped,
+                                                     uint32_t* __restrict__ tmp_start, uint32_t* __restrict__ final_start, uint32_t cap,
+                                                     FastCaps caps, FastMeta* __restrict__ meta) {
+    __shared__ unsigned long long sh[1024];
+    __shared__ uint32_t longest;
+    const uint32_t n = meta->n_cells;
+    if (threadIdx.x == 0) longest = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t c = threadIdx.x; c < n; c += 1024) {
+        const uint32_t v = counts[c];
+        clamped[c] = v < cap ? v : cap;
+        mine = max(mine, v);
+    }
+    atomicMax(&longest, mine);
+    __syncthreads();
+    block_scan_1024(counts, tmp_start, n, sh);
+    const unsigned long long refs = block_scan_1024(clamped, final_start, n, sh);
+    if (threadIdx.x == 0) {
+        meta->max_count = longest;
+        if (refs > caps.refs || longest > FAST_MAX_LIST) {
+            meta->overflow = 1;
+            meta->n_refs = 0;
+            meta->n_pairs = 0;  // the kernels behind this one do nothing
+        } else {
+            meta->n_refs = (uint32_t)refs;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void kf_fill(const FastMeta* __restrict__ meta, const uint32_t* __restrict__ slots,
+                                               const uint32_t* __restrict__ pair_cell, const uint32_t* __restrict__ pair_id,
+                                               const uint32_t* __restrict__ tmp_start, uint32_t* __restrict__ tmp_ids) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= meta->n_pairs) return;
+    tmp_ids[tmp_start[pair_cell[p]] + slots[p]] = pair_id[p];
+}
+
+// Sort, cap and compaction in one step: an id's place in its cell's final list is the number of smaller ids in that
+// cell (ids are distinct inside a cell); places beyond the cap are dropped, which keeps the lowest ids.
+__global__ __launch_bounds__(256) void kf_rank_place(const FastMeta* __restrict__ meta, const uint32_t* __restrict__ pair_cell,
+                                                     const uint32_t* __restrict__ pair_id, const uint32_t* __restrict__ tmp_start,
+                                                     const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ final_start,
+                                                     uint32_t cap, uint32_t* __restrict__ indices, uint32_t* __restrict__ ref_cell) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= meta->n_pairs) return;
+    const uint32_t c = pair_cell[p], id = pair_id[p];
+    const uint32_t a = tmp_start[c], b = tmp_start[c + 1];
+    uint32_t rank = 0;
+    for (uint32_t k = a; k < b; ++k) rank += tmp_ids[k] < id ? 1u : 0u;
+    if (rank < cap) {
+        indices[final_start[c] + rank] = id;
+        ref_cell[final_start[c] + rank] = c;
+    }
+}
+
+// k_emit_cells and k_emit_records with their sizes read from the device.
+__global__ void kf_emit_cells(const FastMeta* __restrict__ meta, const uint32_t* __restrict__ cell_start, uint32_t cap,
+                              uint2* __restrict__ cells) {
+    const uint32_t gx = meta->gx, gy = meta->gy, gz = meta->gz;
+    if (meta->overflow) return;
+    const uint32_t px = gx + 2, py = gy + 2, pz = gz + 2;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (size_t)px * py * pz) return;
+    const uint32_t x = (uint32_t)(p % px), y = (uint32_t)((p / px) % py), z = (uint32_t)(p / ((size_t)px * py));
+    uint2 rec = make_uint2(0u, CELL_SENTINEL);
+    if (x >= 1 && x <= gx && y >= 1 && y <= gy && z >= 1 && z <= gz) {
+        const size_t c = (size_t)(x - 1) + (size_t)(y - 1) * gx + (size_t)(z - 1) * gx * gy;
+        const uint32_t a = cell_start[c], b = cell_start[c + 1];
+        rec = make_uint2(a, b - a < cap ? b - a : cap);
+    }
+    cells[p] = rec;
+}
+
+__global__ void kf_emit_records(const FastMeta* __restrict__ meta, float cell, uint32_t nb, uint32_t nt, int tri_mode,
+                                const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+                                const uint32_t* __restrict__ indices, const uint32_t* __restrict__ ref_cell,
+                                const uint32_t* __restrict__ full_start, uint32_t cap, const uint32_t* __restrict__ tri_mat,
+                                const float4* __restrict__ materials, uint32_t n_materials, float4* __restrict__ refs) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= meta->n_refs) return;
+    emit_record(fast_grid(*meta, cell, nb, nt, tri_mode), boxes, tri_v, indices, ref_cell, full_start, cap, tri_mat, materials,
+                n_materials, refs, r);
+}
+
 }  // namespace
 
 namespace rt {
@@ -413,6 +705,7 @@ int rebuild_trace_records(rt_ctx* c) {
         RT_HIP(c, hipMemcpyAsync(&kept, pos + n_refs, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         RT_HIP(c, hipStreamSynchronize(st));
         c->dup_state = kept < n_refs ? 1 : 0;
+        c->dup_share = (float)(n_refs - kept) / (float)n_refs;
         if (kept < n_refs) {
             RT_HIP(c, c->tc_indices.reserve((size_t)kept * 4 + 16));
             RT_HIP(c, c->tc_ref_cell.reserve((size_t)kept * 4 + 16));
@@ -449,7 +742,134 @@ int rebuild_trace_records(rt_ctx* c) {
     return RT_OK;
 }
 
+
+// Dimensions of the three coarse levels, reported only (src/grid.rs:302-322); their counts are not built.
+static void coarse_dims(GridMetadata& meta, bool tri_mode) {
+    const float cell_size = meta.finest_cell_size;
+    for (uint32_t level = 0; level + 1 < RT_GRID_LEVELS; ++level) {
+        const float cs = cell_size * (float)(1u << (RT_GRID_LEVELS - 1 - level));
+        const float div = tri_mode ? fmaxf(cs, RT_TRI_MIN_CELL_SIZE) : cs;
+        const float ext[3] = {meta.bounds_max[0] - meta.bounds_min[0], meta.bounds_max[1] - meta.bounds_min[1],
+                              meta.bounds_max[2] - meta.bounds_min[2]};
+        for (int k = 0; k < 3; ++k) {
+            float q = ceilf(ext[k] / div);
+            uint64_t v = !(q > 0.0f) ? 0ull : (q >= 4294967296.0f ? 0xFFFFFFFFull : (uint64_t)q);
+            if (tri_mode) v = std::min<uint64_t>(std::max<uint64_t>(v, 1), RT_TRI_MAX_GRID_DIM);
+            meta.grid_sizes[level][k] = (uint32_t)v;
+        }
+    }
+}
+
+// The rebuild without host round trips (see FastMeta above). Returns RT_OK with *done = false when this build has to
+// go through the general path: not eligible, or something did not fit.
+static int build_grid_fast(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode, bool* done) {
+    *done = false;
+    const bool tri_mode = mode == RT_GRID_TRIANGLES;
+    const uint32_t nb = tri_mode ? 0u : c->nb, nt = c->nt, total = nb + nt;
+    // a grid of this scene, mode, cell size and cap has been built before (its buffers are the capacities), and
+    // nothing needs the duplicate search
+    if (getenv("RT_DEBUG_BUILD"))
+        fprintf(stderr, "fast build: ready %d total %u/%u mode %d/%d cell %g/%g cap %u/%u dup %d\n", (int)c->fast_ready, total, c->fast_total,
+                c->grid_mode, mode, c->fast_cell, cell_size, c->build_cap, max_per_cell, c->dup_state);
+    if (!c->fast_ready || total == 0 || total > FAST_MAX_OBJECTS || c->fast_total != total || c->grid_mode != mode ||
+        c->fast_cell != cell_size || c->build_cap != max_per_cell || c->params.max_objects_per_cell < max_per_cell)
+        return RT_OK;
+    // Duplicate triangles: this path does not search for them. Not searched yet -> general path. Found, but they are
+    // less than a twentieth of the references (a model with a few doubled faces) -> tested like any other triangle
+    // here, which changes no answer; a scene made of copies keeps the general path, whose search pays for itself.
+    if (c->params.skip_duplicate_triangles && c->params.collect_stats != 1 && nt > 1 &&
+        (c->dup_state < 0 || (c->dup_state == 1 && c->dup_share > 0.05f)))
+        return RT_OK;
+    auto words = [](const DevBuf& b) { return (uint32_t)std::min<size_t>(b.cap / 4, 0xFFFFFFF0u); };
+    FastCaps caps;
+    caps.cells = std::min({words(c->b_counts), words(c->b_tmp_start), words(c->b_cursor), words(c->cell_start)});
+    caps.cells = caps.cells ? caps.cells - 1 : 0;
+    caps.bordered = (uint32_t)std::min<size_t>(c->cells.cap / sizeof(uint2), 0xFFFFFFF0u);
+    caps.pairs = std::min({words(c->b_flags), words(c->b_tmp_ids), words(c->b_tmp_sorted), words(c->b_tmp_cell)});
+    const size_t ref_recs = c->refs.cap / 48;
+    caps.refs = std::min({words(c->indices), words(c->ref_cell), (uint32_t)std::min<size_t>(ref_recs ? ref_recs - 1 : 0, 0xFFFFFFF0u)});
+    if (!caps.cells || !caps.pairs || !caps.refs || !caps.bordered || words(c->b_obj_n) < total + 1 || words(c->b_obj_off) < total + 1)
+        return RT_OK;
+    hipStream_t st = c->stream;
+    RT_HIP(c, c->fast_meta.reserve(sizeof(FastMeta)));
+    FastMeta* meta = c->fast_meta.as<FastMeta>();
+    const int tm = tri_mode ? 1 : 0;
+    const BoxData* boxes = c->boxes.as<BoxData>();
+    const float* tri_v = c->tri_v.as<float>();
+    uint32_t *counts = c->b_counts.as<uint32_t>(), *tmp_start = c->b_tmp_start.as<uint32_t>(), *clamped = c->b_cursor.as<uint32_t>();
+    uint32_t *final_start = c->cell_start.as<uint32_t>(), *obj_n = c->b_obj_n.as<uint32_t>(), *obj_off = c->b_obj_off.as<uint32_t>();
+    uint32_t *slots = c->b_flags.as<uint32_t>(), *tmp_ids = c->b_tmp_ids.as<uint32_t>(), *pair_id = c->b_tmp_sorted.as<uint32_t>();
+    uint32_t* pair_cell = c->b_tmp_cell.as<uint32_t>();
+    // launches cover what the last build needed plus a margin, never more than the buffers hold: a frame that needs
+    // more raises `overflow` (the pair count is checked against the launch's reach too)
+    auto reach = [](uint32_t last, uint32_t cap) { return std::min<uint64_t>(cap, (uint64_t)last + last / 2 + 4096); };
+    FastCaps lim = caps;
+    lim.cells = (uint32_t)reach(c->n_cells, caps.cells);
+    lim.bordered = (uint32_t)reach(c->fast_bordered, caps.bordered);
+    lim.pairs = (uint32_t)reach(c->fast_pairs, caps.pairs);
+    lim.refs = (uint32_t)reach(c->n_refs, caps.refs);
+    RT_HIP(c, hipMemsetAsync(counts, 0, ((size_t)lim.cells + 1) * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(kf_bounds_dims, dim3(1), dim3(1024), 0, st, boxes, tri_v, nb, total, cell_size, tm, lim, meta);
+    hipLaunchKernelGGL(kf_obj_pairs, dim3((total + 1 + 255) / 256), dim3(256), 0, st, (const FastMeta*)meta, cell_size, nb, nt, tm,
+                       boxes, tri_v, obj_n);
+    hipLaunchKernelGGL(kf_scan_objs, dim3(1), dim3(1024), 0, st, (const uint32_t*)obj_n, obj_off, total, lim, meta);
+    const dim3 pair_grid((lim.pairs + 255) / 256);
+    hipLaunchKernelGGL(kf_bin_count, pair_grid, dim3(256), 0, st, (const FastMeta*)meta, cell_size, nb, nt, tm, boxes, tri_v,
+                       (const uint32_t*)obj_off, counts, slots, pair_cell, pair_id);
+    hipLaunchKernelGGL(kf_scan_cells, dim3(1), dim3(1024), 0, st, (const uint32_t*)counts, clamped, tmp_start, final_start, max_per_cell,
+                       lim, meta);
+    hipLaunchKernelGGL(kf_fill, pair_grid, dim3(256), 0, st, (const FastMeta*)meta, (const uint32_t*)slots, (const uint32_t*)pair_cell,
+                       (const uint32_t*)pair_id, (const uint32_t*)tmp_start, tmp_ids);
+    hipLaunchKernelGGL(kf_rank_place, pair_grid, dim3(256), 0, st, (const FastMeta*)meta, (const uint32_t*)pair_cell,
+                       (const uint32_t*)pair_id, (const uint32_t*)tmp_start, (const uint32_t*)tmp_ids, (const uint32_t*)final_start,
+                       max_per_cell, c->indices.as<uint32_t>(), c->ref_cell.as<uint32_t>());
+    const uint32_t trace_cap = std::min(max_per_cell, c->params.max_objects_per_cell);
+    hipLaunchKernelGGL(kf_emit_cells, dim3((lim.bordered + 255) / 256), dim3(256), 0, st, (const FastMeta*)meta,
+                       (const uint32_t*)final_start, c->params.max_objects_per_cell, c->cells.as<uint2>());
+    hipLaunchKernelGGL(kf_emit_records, dim3((lim.refs + 255) / 256), dim3(256), 0, st, (const FastMeta*)meta, cell_size, nb, nt, tm, boxes,
+                       tri_v, (const uint32_t*)c->indices.as<uint32_t>(), (const uint32_t*)c->ref_cell.as<uint32_t>(),
+                       (const uint32_t*)final_start, trace_cap, c->tri_mat.as<uint32_t>(), c->materials.as<float4>(), c->n_materials,
+                       c->refs.as<float4>());
+    RT_HIP(c, hipGetLastError());
+    FastMeta h;
+    RT_HIP(c, hipMemcpyAsync(&h, meta, sizeof(h), hipMemcpyDeviceToHost, st));
+    RT_HIP(c, hipStreamSynchronize(st));
+    if (getenv("RT_DEBUG_BUILD"))
+        fprintf(stderr, "fast build: overflow %u dims %u %u %u cells %u pairs %u refs %u longest %u | lim cells %u bordered %u pairs %u refs %u\n",
+                h.overflow, h.gx, h.gy, h.gz, h.n_cells, h.n_pairs, h.n_refs, h.max_count, lim.cells, lim.bordered, lim.pairs, lim.refs);
+    if (h.overflow) return RT_OK;  // the general path builds this frame (and leaves larger buffers behind)
+    GridMetadata gm;
+    memset(&gm, 0, sizeof(gm));
+    for (int k = 0; k < 3; ++k) {
+        gm.bounds_min[k] = h.bmin[k];
+        gm.bounds_max[k] = h.bmax[k];
+    }
+    gm.num_levels = RT_GRID_LEVELS;
+    gm.finest_cell_size = cell_size;
+    gm.grid_sizes[RT_GRID_LEVELS - 1][0] = h.gx, gm.grid_sizes[RT_GRID_LEVELS - 1][1] = h.gy, gm.grid_sizes[RT_GRID_LEVELS - 1][2] = h.gz;
+    coarse_dims(gm, tri_mode);
+    c->meta = gm;
+    c->n_cells = h.n_cells;
+    c->n_refs = c->n_refs_t = h.n_refs;
+    c->grid_nb = nb;
+    c->grid_built = true;
+    c->t_cell_start = c->cell_start.as<uint32_t>();
+    c->t_indices = c->indices.as<uint32_t>();
+    c->t_ref_cell = c->ref_cell.as<uint32_t>();
+    c->fast_pairs = h.n_pairs;
+    c->fast_bordered = (h.gx + 2) * (h.gy + 2) * (h.gz + 2);
+    *done = true;
+    return RT_OK;
+}
+
+
 int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mode) {
+    {
+        bool done = false;
+        if (int r = build_grid_fast(c, cell_size, max_per_cell, mode, &done)) return r;
+        c->last_build_fast = done;
+        if (done) return RT_OK;
+    }
     const bool tri_mode = mode == RT_GRID_TRIANGLES;
     const uint32_t nb = tri_mode ? 0u : c->nb;
     const uint32_t nt = c->nt;
@@ -506,21 +926,7 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
     meta.num_levels = RT_GRID_LEVELS;
     meta.finest_cell_size = cell_size;
     for (int k = 0; k < 3; ++k) meta.grid_sizes[RT_GRID_LEVELS - 1][k] = (uint32_t)dims[k];
-    if (!tri_empty) {
-        // coarse level dimensions are reported (src/grid.rs:302-322); their counts are not built
-        for (uint32_t level = 0; level + 1 < RT_GRID_LEVELS; ++level) {
-            const float cs = cell_size * (float)(1u << (RT_GRID_LEVELS - 1 - level));
-            const float div = tri_mode ? fmaxf(cs, RT_TRI_MIN_CELL_SIZE) : cs;
-            const V3 e = bmax - bmin;
-            const float ext[3] = {e.x, e.y, e.z};
-            for (int k = 0; k < 3; ++k) {
-                float q = ceilf(ext[k] / div);
-                uint64_t v = !(q > 0.0f) ? 0ull : (q >= 4294967296.0f ? 0xFFFFFFFFull : (uint64_t)q);
-                if (tri_mode) v = std::min<uint64_t>(std::max<uint64_t>(v, 1), RT_TRI_MAX_GRID_DIM);
-                meta.grid_sizes[level][k] = (uint32_t)v;
-            }
-        }
-    }
+    if (!tri_empty) coarse_dims(meta, tri_mode);
 
     BinGrid g;
     g.bmin[0] = bmin.x, g.bmin[1] = bmin.y, g.bmin[2] = bmin.z;
@@ -644,6 +1050,12 @@ int build_grid_device(rt_ctx* c, float cell_size, uint32_t max_per_cell, int mod
     c->build_cap = max_per_cell;
     if (int r = rebuild_trace_records(c)) return r;
     RT_HIP(c, hipStreamSynchronize(st));
+    // what a later rebuild of this scene may reuse without asking the host for sizes (build_grid_fast)
+    c->fast_ready = n_tmp != 0;
+    c->fast_total = total;
+    c->fast_cell = cell_size;
+    c->fast_pairs = n_tmp;
+    c->fast_bordered = (uint32_t)((dims[0] + 2) * (dims[1] + 2) * (dims[2] + 2));
     return RT_OK;
 }
 

@@ -102,6 +102,7 @@ struct rt_ctx {
     // -1: not looked for yet (new scene or materials); 0: the last search left nothing out, so a rebuild after a
     // vertex update does not search again (an animated mesh pays for one search, not one per frame); 1: found
     int dup_state = -1;
+    float dup_share = 0.0f;  // share of the references the last search left out
     const uint32_t* t_cell_start = nullptr;  // = cell_start or tc_start
     const uint32_t* t_indices = nullptr;     // = indices or tc_indices
     const uint32_t* t_ref_cell = nullptr;    // cell of every entry of t_indices (grids built here only)
@@ -110,6 +111,13 @@ struct rt_ctx {
     rt::DevBuf cells;       // uint2[n_cells]
     rt::DevBuf refs;        // float4[3*n_refs]
     rt::DevBuf box_frame;   // float4[4*nb]
+
+    // state of the rebuild that asks the host for nothing (build_grid_fast in rt_build.hip): valid after a general build
+    bool fast_ready = false;
+    bool last_build_fast = false;
+    uint32_t fast_total = 0, fast_pairs = 0, fast_bordered = 0;
+    float fast_cell = 0.0f;
+    rt::DevBuf fast_meta;
 
     // binning scratch
     rt::DevBuf b_partial, b_counts, b_tmp_start, b_cursor, b_tmp_ids, b_tmp_sorted, b_tmp_cell, b_scan_tmp, b_flags,

@@ -191,6 +191,12 @@ class TraceCore:
         self._ck(self._L.rt_get_grid(self._h, C.byref(meta), C.byref(nc), C.byref(nr)))
         return meta, nc.value, nr.value
 
+    def build_path(self):
+        """0: general build, 1: rebuild with every size kept on the device, -1: grid supplied by the caller."""
+        v = C.c_int()
+        self._ck(self._L.rt_get_build_path(self._h, C.byref(v)))
+        return v.value
+
     def read_grid_csr(self):
         _, nc, nr = self.grid_info()
         cell_start, indices = np.empty(nc + 1, np.uint32), np.empty(nr, np.uint32)

@@ -689,7 +689,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
                       &c->b_tmp_sorted, &c->b_tmp_cell, &c->b_scan_tmp, &c->b_flags, &c->b_obj_n, &c->b_obj_off, &c->b_obj_sum, &c->out_p,     &c->out_s,
                       &c->in_o,      &c->in_d,      &c->stats,      &c->misc,      &c->tri_uv,    &c->texels,    &c->tc_start,  &c->tc_indices, &c->tc_pos, &c->dd_keys, &c->dd_keys2,
-                      &c->dd_vals, &c->dd_vals2, &c->dd_flag, &c->dd_head, &c->dd_dup, &c->ref_cell, &c->tc_ref_cell, &c->fast_meta};
+                      &c->dd_vals, &c->dd_vals2, &c->dd_flag, &c->dd_head, &c->dd_dup, &c->ref_cell, &c->tc_ref_cell, &c->fast_meta, &c->fast_scan};
     for (DevBuf* b : bufs) b->release();
     for (rt_table* t : c->tables) {
         t->buf.release();

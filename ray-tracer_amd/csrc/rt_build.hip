@@ -373,7 +373,7 @@ __global__ void k_compact_starts(const uint32_t* __restrict__ cell_start, const 
 // rt_build_grid). The general path above asks the host for sizes four times per build (bounds -> dimensions, pair
 // count, reference count, duplicates) and goes through about thirty launches; for a scene of a few thousand triangles
 // those waits and launch gaps cost more than the kernels. This path keeps every size on the device (FastMeta), launches
-// over the CAPACITY of the buffers the last build left behind, and reads 64 bytes back once, at the end. Whatever does
+// over the CAPACITY of the buffers the last build left behind, and reads a few words back once, at the end. Whatever does
 // not fit - more cells, pairs or references than the buffers hold, a cell list too long for the quadratic ranking
 // below - raises `overflow`, and the host then runs the general path, which is exact for everything. The cell lists
 // are the same either way: same bounds (min / max are order-independent), same dimensions (the same correctly rounded
@@ -381,10 +381,10 @@ __global__ void k_compact_starts(const uint32_t* __restrict__ cell_start, const 
 struct FastMeta {
     float bmin[3], bmax[3];
     uint32_t gx, gy, gz, n_cells;
-    uint32_t n_pairs, n_refs, overflow, max_count;
-    uint32_t pad[2];
+    uint32_t n_refs, overflow;
+    unsigned long long n_pairs;  // summed in 64 bits: a total that does not fit must be seen, not wrapped
 };
-static_assert(sizeof(FastMeta) == 64, "FastMeta is read back as 64 bytes");
+static_assert(sizeof(FastMeta) == 56, "FastMeta: one small read-back at the end of a build");
 
 struct FastCaps {
     uint32_t cells;     // entries of the per-cell arrays minus one
@@ -459,12 +459,16 @@ __global__ __launch_bounds__(1024) void kf_bounds_dims(const BoxData* __restrict
     *meta = m;
 }
 
-__global__ __launch_bounds__(256) void kf_obj_pairs(const FastMeta* __restrict__ meta, float cell, uint32_t nb, uint32_t nt, int tri_mode,
+__global__ __launch_bounds__(256) void kf_obj_pairs(FastMeta* __restrict__ meta, float cell, uint32_t nb, uint32_t nt, int tri_mode,
                                                     const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
-                                                    uint32_t* __restrict__ obj_n) {
+                                                    uint32_t* __restrict__ obj_n, uint32_t* __restrict__ counts, uint32_t n_counts) {
+    __shared__ unsigned long long wg_sum;
+    if (threadIdx.x == 0) wg_sum = 0;
+    __syncthreads();
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    // the per-cell counters start at zero (the counting kernel runs two launches later)
+    for (uint32_t k = id; k < n_counts; k += gridDim.x * blockDim.x) counts[k] = 0;
     const uint32_t total = nb + nt;
-    if (id > total) return;
     uint32_t n = 0;
     if (id < total && !meta->overflow) {
         const BinGrid g = fast_grid(*meta, cell, nb, nt, tri_mode);
@@ -475,59 +479,23 @@ __global__ __launch_bounds__(256) void kf_obj_pairs(const FastMeta* __restrict__
                                      (unsigned long long)(r.hi[2] - r.lo[2] + 1);
         n = r.lo[0] > r.hi[0] ? 0u : (v > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)v);
     }
-    obj_n[id] = n;
-}
-
-// Exclusive scan of n + 1 words by one workgroup (64-bit running sums: an overflowing total must be seen, not wrapped).
-// in[n] is the closing element (its value is ignored, out[n] = total). Returns the total in every thread.
-__device__ inline unsigned long long block_scan_1024(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
-                                                     unsigned long long* sh /* 1024 */) {
-    const uint32_t t = threadIdx.x;
-    const uint32_t chunk = (n + 1023) / 1024;
-    const uint32_t a = min(t * chunk, n), b = min(a + chunk, n);
-    unsigned long long sum = 0;
-    for (uint32_t k = a; k < b; ++k) sum += in[k];
-    sh[t] = sum;
+    if (id <= total) obj_n[id] = n;  // entry `total` closes the scan
+    if (n) atomicAdd(&wg_sum, (unsigned long long)n);
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive scan of the 1024 partial sums
-        const unsigned long long v = t >= off ? sh[t - off] : 0ull;
-        __syncthreads();
-        sh[t] += v;
-        __syncthreads();
-    }
-    const unsigned long long total = sh[1023];
-    unsigned long long run = sh[t] - sum;
-    for (uint32_t k = a; k < b; ++k) {
-        const uint32_t v = in[k];
-        out[k] = (uint32_t)run;
-        run += v;
-    }
-    if (t == 0) out[n] = (uint32_t)total;
-    __syncthreads();
-    return total;
-}
-
-__global__ __launch_bounds__(1024) void kf_scan_objs(const uint32_t* __restrict__ obj_n, uint32_t* __restrict__ obj_off, uint32_t total,
-                                                    FastCaps caps, FastMeta* __restrict__ meta) {
-    __shared__ unsigned long long sh[1024];
-    const unsigned long long pairs = block_scan_1024(obj_n, obj_off, total, sh);
-    if (threadIdx.x == 0) {
-        if (pairs > caps.pairs) {
-            meta->overflow = 1;
-            meta->n_pairs = 0;
-        } else {
-            meta->n_pairs = (uint32_t)pairs;
-        }
-    }
+    if (threadIdx.x == 0 && wg_sum) atomicAdd(&meta->n_pairs, wg_sum);
 }
 
 // One lane per (object, cell) pair: the pair's cell, id and its slot in the cell's list (arbitrary order).
-__global__ __launch_bounds__(256) void kf_bin_count(const FastMeta* __restrict__ meta, float cell, uint32_t nb, uint32_t nt, int tri_mode,
-                                                    const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
+__global__ __launch_bounds__(256) void kf_bin_count(FastMeta* __restrict__ meta, FastCaps caps, float cell, uint32_t nb, uint32_t nt,
+                                                    int tri_mode, const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
                                                     const uint32_t* __restrict__ obj_off, uint32_t* __restrict__ counts,
                                                     uint32_t* __restrict__ slots, uint32_t* __restrict__ pair_cell,
                                                     uint32_t* __restrict__ pair_id) {
-    const uint32_t n_pairs = meta->n_pairs;
+    if (meta->n_pairs > caps.pairs) {  // more pairs than the buffers (and this launch) cover
+        if (blockIdx.x == 0 && threadIdx.x == 0) meta->overflow = 1;
+        return;
+    }
+    const uint32_t n_pairs = (uint32_t)meta->n_pairs;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x * blockDim.x >= n_pairs) return;  // whole workgroup
     __shared__ uint32_t window[2];
@@ -562,56 +530,50 @@ __global__ __launch_bounds__(256) void kf_bin_count(const FastMeta* __restrict__
     pair_id[p] = id;
 }
 
-// One workgroup: where every cell's unsorted ids go (scan of the counts) and where its kept ids go (scan of the counts
-// cut to the cap); the reference count; the longest list.
-__global__ __launch_bounds__(1024) void kf_scan_cells(const uint32_t* __restrict__ counts, uint32_t* __restrict__ clamped,
-                                                     uint32_t* __restrict__ tmp_start, uint32_t* __restrict__ final_start, uint32_t cap,
-                                                     FastCaps caps, FastMeta* __restrict__ meta) {
-    __shared__ unsigned long long sh[1024];
-    __shared__ uint32_t longest;
-    const uint32_t n = meta->n_cells;
-    if (threadIdx.x == 0) longest = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t c = threadIdx.x; c < n; c += 1024) {
-        const uint32_t v = counts[c];
-        clamped[c] = v < cap ? v : cap;
-        mine = max(mine, v);
-    }
-    atomicMax(&longest, mine);
-    __syncthreads();
-    block_scan_1024(counts, tmp_start, n, sh);
-    const unsigned long long refs = block_scan_1024(clamped, final_start, n, sh);
-    if (threadIdx.x == 0) {
-        meta->max_count = longest;
-        if (refs > caps.refs || longest > FAST_MAX_LIST) {
-            meta->overflow = 1;
-            meta->n_refs = 0;
-            meta->n_pairs = 0;  // the kernels behind this one do nothing
-        } else {
-            meta->n_refs = (uint32_t)refs;
-        }
-    }
-}
+// The two prefix sums every cell needs travel through ONE scan as the halves of a 64-bit word: where the cell's unsorted
+// ids go (sum of the counts, high half) and where its kept ids go (sum of the counts cut to the cap, low half). Neither
+// half can carry into the other: both totals are at most the pair count, below 2^32.
+struct PackCounts {
+    uint32_t cap;
+    __device__ unsigned long long operator()(uint32_t v) const { return ((unsigned long long)v << 32) | (v < cap ? v : cap); }
+};
 
-__global__ __launch_bounds__(256) void kf_fill(const FastMeta* __restrict__ meta, const uint32_t* __restrict__ slots,
-                                               const uint32_t* __restrict__ pair_cell, const uint32_t* __restrict__ pair_id,
-                                               const uint32_t* __restrict__ tmp_start, uint32_t* __restrict__ tmp_ids) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= meta->n_pairs) return;
-    tmp_ids[tmp_start[pair_cell[p]] + slots[p]] = pair_id[p];
+// Thread t has two jobs: entry t of the scan is split into the two 32-bit prefix arrays the later kernels and
+// rt_read_grid_csr read, and pair t's id goes to its slot of its cell's unsorted list (the place comes straight from
+// the scanned word: the split of that cell may not have happened yet).
+__global__ __launch_bounds__(256) void kf_split_fill(FastMeta* __restrict__ meta, const unsigned long long* __restrict__ scanned,
+                                                     uint32_t n_entries, uint32_t* __restrict__ tmp_start, uint32_t* __restrict__ final_start,
+                                                     const uint32_t* __restrict__ slots, const uint32_t* __restrict__ pair_cell,
+                                                     const uint32_t* __restrict__ pair_id, uint32_t* __restrict__ tmp_ids) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_entries) {
+        const unsigned long long v = scanned[t];
+        tmp_start[t] = (uint32_t)(v >> 32);
+        final_start[t] = (uint32_t)v;
+        if (t == meta->n_cells) meta->n_refs = (uint32_t)v;
+    }
+    if (!meta->overflow && t < meta->n_pairs) tmp_ids[(uint32_t)(scanned[pair_cell[t]] >> 32) + slots[t]] = pair_id[t];
 }
 
 // Sort, cap and compaction in one step: an id's place in its cell's final list is the number of smaller ids in that
-// cell (ids are distinct inside a cell); places beyond the cap are dropped, which keeps the lowest ids.
-__global__ __launch_bounds__(256) void kf_rank_place(const FastMeta* __restrict__ meta, const uint32_t* __restrict__ pair_cell,
+// cell (ids are distinct inside a cell); places beyond the cap are dropped, which keeps the lowest ids. A list too long
+// for this quadratic count, or more references than the buffers hold, raises `overflow`.
+__global__ __launch_bounds__(256) void kf_rank_place(FastMeta* __restrict__ meta, FastCaps caps, const uint32_t* __restrict__ pair_cell,
                                                      const uint32_t* __restrict__ pair_id, const uint32_t* __restrict__ tmp_start,
                                                      const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ final_start,
                                                      uint32_t cap, uint32_t* __restrict__ indices, uint32_t* __restrict__ ref_cell) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= meta->n_pairs) return;
+    if (meta->overflow || p >= meta->n_pairs) return;
+    if (meta->n_refs > caps.refs) {
+        meta->overflow = 1;
+        return;
+    }
     const uint32_t c = pair_cell[p], id = pair_id[p];
     const uint32_t a = tmp_start[c], b = tmp_start[c + 1];
+    if (b - a > FAST_MAX_LIST) {
+        meta->overflow = 1;
+        return;
+    }
     uint32_t rank = 0;
     for (uint32_t k = a; k < b; ++k) rank += tmp_ids[k] < id ? 1u : 0u;
     if (rank < cap) {
@@ -620,33 +582,29 @@ __global__ __launch_bounds__(256) void kf_rank_place(const FastMeta* __restrict_
     }
 }
 
-// k_emit_cells and k_emit_records with their sizes read from the device.
-__global__ void kf_emit_cells(const FastMeta* __restrict__ meta, const uint32_t* __restrict__ cell_start, uint32_t cap,
-                              uint2* __restrict__ cells) {
-    const uint32_t gx = meta->gx, gy = meta->gy, gz = meta->gz;
+// k_emit_cells and k_emit_records in one launch, their sizes read from the device: thread t writes bordered cell record
+// t and reference record t, whichever of the two exist.
+__global__ void kf_emit(const FastMeta* __restrict__ meta, float cell, uint32_t nb, uint32_t nt, int tri_mode, const BoxData* __restrict__ boxes,
+                        const float* __restrict__ tri_v, const uint32_t* __restrict__ indices, const uint32_t* __restrict__ ref_cell,
+                        const uint32_t* __restrict__ final_start, uint32_t list_cap, uint32_t mask_cap, const uint32_t* __restrict__ tri_mat,
+                        const float4* __restrict__ materials, uint32_t n_materials, uint2* __restrict__ cells, float4* __restrict__ refs) {
     if (meta->overflow) return;
+    const uint32_t gx = meta->gx, gy = meta->gy, gz = meta->gz;
     const uint32_t px = gx + 2, py = gy + 2, pz = gz + 2;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= (size_t)px * py * pz) return;
-    const uint32_t x = (uint32_t)(p % px), y = (uint32_t)((p / px) % py), z = (uint32_t)(p / ((size_t)px * py));
-    uint2 rec = make_uint2(0u, CELL_SENTINEL);
-    if (x >= 1 && x <= gx && y >= 1 && y <= gy && z >= 1 && z <= gz) {
-        const size_t c = (size_t)(x - 1) + (size_t)(y - 1) * gx + (size_t)(z - 1) * gx * gy;
-        const uint32_t a = cell_start[c], b = cell_start[c + 1];
-        rec = make_uint2(a, b - a < cap ? b - a : cap);
+    if (p < (size_t)px * py * pz) {
+        const uint32_t x = (uint32_t)(p % px), y = (uint32_t)((p / px) % py), z = (uint32_t)(p / ((size_t)px * py));
+        uint2 rec = make_uint2(0u, CELL_SENTINEL);
+        if (x >= 1 && x <= gx && y >= 1 && y <= gy && z >= 1 && z <= gz) {
+            const size_t c = (size_t)(x - 1) + (size_t)(y - 1) * gx + (size_t)(z - 1) * gx * gy;
+            const uint32_t a = final_start[c], b = final_start[c + 1];
+            rec = make_uint2(a, b - a < list_cap ? b - a : list_cap);
+        }
+        cells[p] = rec;
     }
-    cells[p] = rec;
-}
-
-__global__ void kf_emit_records(const FastMeta* __restrict__ meta, float cell, uint32_t nb, uint32_t nt, int tri_mode,
-                                const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
-                                const uint32_t* __restrict__ indices, const uint32_t* __restrict__ ref_cell,
-                                const uint32_t* __restrict__ full_start, uint32_t cap, const uint32_t* __restrict__ tri_mat,
-                                const float4* __restrict__ materials, uint32_t n_materials, float4* __restrict__ refs) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= meta->n_refs) return;
-    emit_record(fast_grid(*meta, cell, nb, nt, tri_mode), boxes, tri_v, indices, ref_cell, full_start, cap, tri_mat, materials,
-                n_materials, refs, r);
+    if (p < meta->n_refs)
+        emit_record(fast_grid(*meta, cell, nb, nt, tri_mode), boxes, tri_v, indices, ref_cell, final_start, mask_cap, tri_mat, materials,
+                    n_materials, refs, (uint32_t)p);
 }
 
 }  // namespace
@@ -782,7 +740,7 @@ static int build_grid_fast(rt_ctx* c, float cell_size, uint32_t max_per_cell, in
         return RT_OK;
     auto words = [](const DevBuf& b) { return (uint32_t)std::min<size_t>(b.cap / 4, 0xFFFFFFF0u); };
     FastCaps caps;
-    caps.cells = std::min({words(c->b_counts), words(c->b_tmp_start), words(c->b_cursor), words(c->cell_start)});
+    caps.cells = std::min({words(c->b_counts), words(c->b_tmp_start), words(c->cell_start)});
     caps.cells = caps.cells ? caps.cells - 1 : 0;
     caps.bordered = (uint32_t)std::min<size_t>(c->cells.cap / sizeof(uint2), 0xFFFFFFF0u);
     caps.pairs = std::min({words(c->b_flags), words(c->b_tmp_ids), words(c->b_tmp_sorted), words(c->b_tmp_cell)});
@@ -796,7 +754,7 @@ static int build_grid_fast(rt_ctx* c, float cell_size, uint32_t max_per_cell, in
     const int tm = tri_mode ? 1 : 0;
     const BoxData* boxes = c->boxes.as<BoxData>();
     const float* tri_v = c->tri_v.as<float>();
-    uint32_t *counts = c->b_counts.as<uint32_t>(), *tmp_start = c->b_tmp_start.as<uint32_t>(), *clamped = c->b_cursor.as<uint32_t>();
+    uint32_t *counts = c->b_counts.as<uint32_t>(), *tmp_start = c->b_tmp_start.as<uint32_t>();
     uint32_t *final_start = c->cell_start.as<uint32_t>(), *obj_n = c->b_obj_n.as<uint32_t>(), *obj_off = c->b_obj_off.as<uint32_t>();
     uint32_t *slots = c->b_flags.as<uint32_t>(), *tmp_ids = c->b_tmp_ids.as<uint32_t>(), *pair_id = c->b_tmp_sorted.as<uint32_t>();
     uint32_t* pair_cell = c->b_tmp_cell.as<uint32_t>();
@@ -808,35 +766,43 @@ static int build_grid_fast(rt_ctx* c, float cell_size, uint32_t max_per_cell, in
     lim.bordered = (uint32_t)reach(c->fast_bordered, caps.bordered);
     lim.pairs = (uint32_t)reach(c->fast_pairs, caps.pairs);
     lim.refs = (uint32_t)reach(c->n_refs, caps.refs);
-    RT_HIP(c, hipMemsetAsync(counts, 0, ((size_t)lim.cells + 1) * sizeof(uint32_t), st));
     hipLaunchKernelGGL(kf_bounds_dims, dim3(1), dim3(1024), 0, st, boxes, tri_v, nb, total, cell_size, tm, lim, meta);
-    hipLaunchKernelGGL(kf_obj_pairs, dim3((total + 1 + 255) / 256), dim3(256), 0, st, (const FastMeta*)meta, cell_size, nb, nt, tm,
-                       boxes, tri_v, obj_n);
-    hipLaunchKernelGGL(kf_scan_objs, dim3(1), dim3(1024), 0, st, (const uint32_t*)obj_n, obj_off, total, lim, meta);
+    hipLaunchKernelGGL(kf_obj_pairs, dim3((total + 1 + 255) / 256), dim3(256), 0, st, meta, cell_size, nb, nt, tm, boxes, tri_v, obj_n, counts,
+                       lim.cells + 1);
+    // the scans run over sizes the host knows - the object count, and the CAPACITY of the per-cell arrays (entries past the
+    // grid's last cell are zero, so every prefix up to it is what a scan of the exact length would give)
+    size_t bytes = 0;
+    RT_HIP(c, rocprim::exclusive_scan(nullptr, bytes, obj_n, obj_off, 0u, (size_t)total + 1, rocprim::plus<uint32_t>(), st));
+    RT_HIP(c, c->b_scan_tmp.reserve(bytes + 256));
+    RT_HIP(c, rocprim::exclusive_scan(c->b_scan_tmp.p, bytes, obj_n, obj_off, 0u, (size_t)total + 1, rocprim::plus<uint32_t>(), st));
     const dim3 pair_grid((lim.pairs + 255) / 256);
-    hipLaunchKernelGGL(kf_bin_count, pair_grid, dim3(256), 0, st, (const FastMeta*)meta, cell_size, nb, nt, tm, boxes, tri_v,
-                       (const uint32_t*)obj_off, counts, slots, pair_cell, pair_id);
-    hipLaunchKernelGGL(kf_scan_cells, dim3(1), dim3(1024), 0, st, (const uint32_t*)counts, clamped, tmp_start, final_start, max_per_cell,
-                       lim, meta);
-    hipLaunchKernelGGL(kf_fill, pair_grid, dim3(256), 0, st, (const FastMeta*)meta, (const uint32_t*)slots, (const uint32_t*)pair_cell,
-                       (const uint32_t*)pair_id, (const uint32_t*)tmp_start, tmp_ids);
-    hipLaunchKernelGGL(kf_rank_place, pair_grid, dim3(256), 0, st, (const FastMeta*)meta, (const uint32_t*)pair_cell,
-                       (const uint32_t*)pair_id, (const uint32_t*)tmp_start, (const uint32_t*)tmp_ids, (const uint32_t*)final_start,
-                       max_per_cell, c->indices.as<uint32_t>(), c->ref_cell.as<uint32_t>());
+    hipLaunchKernelGGL(kf_bin_count, pair_grid, dim3(256), 0, st, meta, lim, cell_size, nb, nt, tm, boxes, tri_v, (const uint32_t*)obj_off,
+                       counts, slots, pair_cell, pair_id);
+    const size_t n_entries = (size_t)lim.cells + 1;
+    RT_HIP(c, c->fast_scan.reserve(n_entries * sizeof(unsigned long long)));
+    unsigned long long* scanned = c->fast_scan.as<unsigned long long>();
+    auto packed = rocprim::make_transform_iterator((const uint32_t*)counts, PackCounts{max_per_cell});
+    RT_HIP(c, rocprim::exclusive_scan(nullptr, bytes, packed, scanned, 0ull, n_entries, rocprim::plus<unsigned long long>(), st));
+    RT_HIP(c, c->b_scan_tmp.reserve(bytes + 256));
+    RT_HIP(c, rocprim::exclusive_scan(c->b_scan_tmp.p, bytes, packed, scanned, 0ull, n_entries, rocprim::plus<unsigned long long>(), st));
+    hipLaunchKernelGGL(kf_split_fill, dim3((uint32_t)((std::max<size_t>(n_entries, lim.pairs) + 255) / 256)), dim3(256), 0, st, meta,
+                       (const unsigned long long*)scanned, (uint32_t)n_entries, tmp_start, final_start, (const uint32_t*)slots,
+                       (const uint32_t*)pair_cell, (const uint32_t*)pair_id, tmp_ids);
+    hipLaunchKernelGGL(kf_rank_place, pair_grid, dim3(256), 0, st, meta, lim, (const uint32_t*)pair_cell, (const uint32_t*)pair_id,
+                       (const uint32_t*)tmp_start, (const uint32_t*)tmp_ids, (const uint32_t*)final_start, max_per_cell,
+                       c->indices.as<uint32_t>(), c->ref_cell.as<uint32_t>());
     const uint32_t trace_cap = std::min(max_per_cell, c->params.max_objects_per_cell);
-    hipLaunchKernelGGL(kf_emit_cells, dim3((lim.bordered + 255) / 256), dim3(256), 0, st, (const FastMeta*)meta,
-                       (const uint32_t*)final_start, c->params.max_objects_per_cell, c->cells.as<uint2>());
-    hipLaunchKernelGGL(kf_emit_records, dim3((lim.refs + 255) / 256), dim3(256), 0, st, (const FastMeta*)meta, cell_size, nb, nt, tm, boxes,
-                       tri_v, (const uint32_t*)c->indices.as<uint32_t>(), (const uint32_t*)c->ref_cell.as<uint32_t>(),
-                       (const uint32_t*)final_start, trace_cap, c->tri_mat.as<uint32_t>(), c->materials.as<float4>(), c->n_materials,
-                       c->refs.as<float4>());
+    hipLaunchKernelGGL(kf_emit, dim3((std::max(lim.bordered, lim.refs) + 255) / 256), dim3(256), 0, st, (const FastMeta*)meta, cell_size, nb, nt,
+                       tm, boxes, tri_v, (const uint32_t*)c->indices.as<uint32_t>(), (const uint32_t*)c->ref_cell.as<uint32_t>(),
+                       (const uint32_t*)final_start, c->params.max_objects_per_cell, trace_cap, c->tri_mat.as<uint32_t>(),
+                       c->materials.as<float4>(), c->n_materials, c->cells.as<uint2>(), c->refs.as<float4>());
     RT_HIP(c, hipGetLastError());
     FastMeta h;
     RT_HIP(c, hipMemcpyAsync(&h, meta, sizeof(h), hipMemcpyDeviceToHost, st));
     RT_HIP(c, hipStreamSynchronize(st));
     if (getenv("RT_DEBUG_BUILD"))
-        fprintf(stderr, "fast build: overflow %u dims %u %u %u cells %u pairs %u refs %u longest %u | lim cells %u bordered %u pairs %u refs %u\n",
-                h.overflow, h.gx, h.gy, h.gz, h.n_cells, h.n_pairs, h.n_refs, h.max_count, lim.cells, lim.bordered, lim.pairs, lim.refs);
+        fprintf(stderr, "fast build: overflow %u dims %u %u %u cells %u pairs %llu refs %u | lim cells %u bordered %u pairs %u refs %u\n",
+                h.overflow, h.gx, h.gy, h.gz, h.n_cells, h.n_pairs, h.n_refs, lim.cells, lim.bordered, lim.pairs, lim.refs);
     if (h.overflow) return RT_OK;  // the general path builds this frame (and leaves larger buffers behind)
     GridMetadata gm;
     memset(&gm, 0, sizeof(gm));
@@ -856,7 +822,7 @@ static int build_grid_fast(rt_ctx* c, float cell_size, uint32_t max_per_cell, in
     c->t_cell_start = c->cell_start.as<uint32_t>();
     c->t_indices = c->indices.as<uint32_t>();
     c->t_ref_cell = c->ref_cell.as<uint32_t>();
-    c->fast_pairs = h.n_pairs;
+    c->fast_pairs = (uint32_t)h.n_pairs;
     c->fast_bordered = (h.gx + 2) * (h.gy + 2) * (h.gz + 2);
     *done = true;
     return RT_OK;

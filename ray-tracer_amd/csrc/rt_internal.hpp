@@ -117,7 +117,7 @@ struct rt_ctx {
     bool last_build_fast = false;
     uint32_t fast_total = 0, fast_pairs = 0, fast_bordered = 0;
     float fast_cell = 0.0f;
-    rt::DevBuf fast_meta;
+    rt::DevBuf fast_meta, fast_scan;
 
     // binning scratch
     rt::DevBuf b_partial, b_counts, b_tmp_start, b_cursor, b_tmp_ids, b_tmp_sorted, b_tmp_cell, b_scan_tmp, b_flags,

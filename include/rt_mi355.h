@@ -114,6 +114,8 @@ typedef struct rt_stats {
     uint64_t cell_records_fetched; /* 8-byte cell records loaded, summed over lanes */
     uint64_t ref_records_fetched;  /* 48-byte reference records loaded by a lane for itself (look-ahead included) */
     uint64_t ref_records_staged;   /* 48-byte reference records copied into LDS once for a whole wave */
+    uint64_t cell_records_uniform; /* of cell_records_fetched: fetched in a step in which every active lane of the wave
+                                      asked for the same record (the rays of a wave's 8x8 pixels walk together) */
 } rt_stats;
 
 /* ---- lifecycle ------------------------------------------------------------------ */

@@ -79,7 +79,7 @@ class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("primary_hits", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("shadow_hits", C.c_uint64), ("cells_visited", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("box_tests", C.c_uint64), ("cell_records_fetched", C.c_uint64), ("ref_records_fetched", C.c_uint64),
-                ("ref_records_staged", C.c_uint64)]
+                ("ref_records_staged", C.c_uint64), ("cell_records_uniform", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -436,6 +436,7 @@ int fetch_stats(rt_ctx* c) {
     c->last_stats.cell_records_fetched = v[7];
     c->last_stats.ref_records_fetched = v[8];
     c->last_stats.ref_records_staged = v[9];
+    c->last_stats.cell_records_uniform = v[10];
     return RT_OK;
 }
 

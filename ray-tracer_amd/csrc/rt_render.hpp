@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, SINGLE ? 8 : RT_RENDER_WAVES) void k_render(De
     const bool live = in_tile && px < f.width && py < f.height;
 
     uint32_t rgba = 0;
-    Counters ctr{0, 0, 0, 0, 0, 0, 0};
+    Counters ctr{};
     // rays, primary hits, shadow rays, shadow hits of this pixel: at most 8 bounces, so a byte each in one register
     uint32_t counts = 0;
     if (live) {

@@ -99,6 +99,7 @@ struct Counters {
     // STATS == 2: what this lane asked the memory system for - cell records (8 bytes each), reference records read
     // directly (48 bytes each, the look-ahead record included) and reference records copied into LDS for the wave
     uint32_t cell_recs, ref_recs, staged_recs;
+    uint32_t cell_recs_uniform;  // of cell_recs: fetched while every active lane of the wave asked for the same record
 };
 
 struct HitRec {
@@ -117,6 +118,9 @@ __device__ v4i llvm_struct_buffer_load_v4i32(v4i rsrc, int vindex, int voffset, 
     "llvm.amdgcn.struct.buffer.load.v4i32");
 __device__ v2i llvm_struct_buffer_load_v2i32(v4i rsrc, int vindex, int voffset, int soffset, int aux) __asm(
     "llvm.amdgcn.struct.buffer.load.v2i32");
+
+// Scalar buffer load (s_buffer_load_dwordx2): for an offset that is the same in every lane. Read-only use.
+__device__ v2i llvm_s_buffer_load_v2i32(v4i rsrc, int offset, int aux) __asm("llvm.amdgcn.s.buffer.load.v2i32");
 
 __device__ inline v4i make_rsrc(const void* base, uint32_t stride, uint32_t num_records) {
     const uint64_t b = (uint64_t)base;
@@ -189,7 +193,11 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             return buf_load16<16 * Q>(refs_d, r);
     };
     auto cell_rec = [&](uint32_t idx) -> uint2 {
-        if (STATS == 2) ctr.cell_recs++;
+        if (STATS == 2) {
+            ctr.cell_recs++;
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+            if (__builtin_amdgcn_ballot_w64(idx == first) == __builtin_amdgcn_ballot_w64(true)) ctr.cell_recs_uniform++;
+        }
         if constexpr (WIDE)
             return s.cells[idx];
         else
@@ -467,7 +475,12 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         t_max.x += ax ? t_delta.x : 0.0f;
         t_max.y += ay ? t_delta.y : 0.0f;
         t_max.z += az ? t_delta.z : 0.0f;
-        cell = cell_rec(idx);
+        if constexpr (X == 4) {  // timing probe only (wrong answers): every lane takes the first lane's cell record, by a scalar load
+            const v2i v = llvm_s_buffer_load_v2i32(cells_d, __builtin_amdgcn_readfirstlane((int)idx) * 8, 0);
+            cell = make_uint2((uint32_t)v.x, (uint32_t)v.y);
+        } else {
+            cell = cell_rec(idx);
+        }
         if (stop) cell.y = CELL_SENTINEL;
     }
     out = HitRec{closest, best_id, best_ref};
@@ -504,9 +517,9 @@ __device__ inline V3 primary_dir(const DevFrame& f, uint32_t px, uint32_t py) {
 // Wave-level sum of per-lane counters, one atomic per wave per counter.
 __device__ inline void flush_stats(unsigned long long* stats, unsigned long long rays, unsigned long long phits,
                                    unsigned long long srays, unsigned long long shits, const Counters& c) {
-    unsigned long long v[10] = {rays, phits, srays, shits, c.cells, c.tri, c.box, c.cell_recs, c.ref_recs, c.staged_recs};
+    unsigned long long v[11] = {rays, phits, srays, shits, c.cells, c.tri, c.box, c.cell_recs, c.ref_recs, c.staged_recs, c.cell_recs_uniform};
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
+    for (int k = 0; k < 11; ++k) {
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         if ((threadIdx.x & 63) == 0 && x) atomicAdd(&stats[k], x);
@@ -534,7 +547,7 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
     const bool live = in_tile && px < f.width && py < f.height;
 
     uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
-    Counters ctr{0, 0, 0, 0, 0, 0, 0};
+    Counters ctr{};
     unsigned long long n_rays = 0, n_ph = 0, n_sr = 0, n_sh = 0;
     if (live) {
         const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
@@ -589,7 +602,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __r
                                                     const float* __restrict__ dirs, uint32_t n,
                                                     uint2* __restrict__ out, unsigned long long* stats) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    Counters ctr{0, 0, 0, 0, 0, 0, 0};
+    Counters ctr{};
     unsigned long long n_rays = 0, n_hit = 0;
     if (i < n) {
         HitRec h;
@@ -609,7 +622,7 @@ __global__ void k_debug_pixel(DevScene s, DevFrame f, uint32_t px, uint32_t py, 
     const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
     const V3 d = primary_dir(f, px, py);
     HitRec h;
-    Counters ctr{0, 0, 0, 0, 0, 0, 0};
+    Counters ctr{};
     const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
     const bool hit = trace_ray<WGSL, false, 1, true, true, WIDE>(s, o, rd, h, ctr);
     for (int k = 0; k < 20; ++k) info20[k] = 0.0f;

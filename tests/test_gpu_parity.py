@@ -454,7 +454,7 @@ def test_stats_equal_oracle_counts(core, ob, rt, car_xyz9):
     _, _, st = check_frame(core, ob, scene, cam, 240, 135, what="stats")
     got = core.stats()
     assert {k: got[k] for k in st} == st, (got, st)
-    assert got["cell_records_fetched"] == got["ref_records_fetched"] == got["ref_records_staged"] == 0
+    assert got["cell_records_fetched"] == got["ref_records_fetched"] == got["ref_records_staged"] == got["cell_records_uniform"] == 0
     # mode 2: the shipped kernels' own fetches (re-test skipping, look-ahead, staging): same answers, rays and hits
     # as counted above, no more candidate records asked for than twice the reference's tests plus one per visited cell
     core.set_collect_stats(2)
@@ -463,6 +463,7 @@ def test_stats_equal_oracle_counts(core, ob, rt, car_xyz9):
     assert all(mov[k] == st[k] for k in ("rays", "primary_hits", "shadow_rays", "shadow_hits"))
     assert mov["cells_visited"] == mov["tri_tests"] == mov["box_tests"] == 0
     assert st["cells_visited"] <= mov["cell_records_fetched"] <= st["cells_visited"] + st["rays"]
+    assert 0 < mov["cell_records_uniform"] <= mov["cell_records_fetched"]
     assert 0 < mov["ref_records_fetched"] + mov["ref_records_staged"] <= 2 * st["tri_tests"] + st["cells_visited"]
     core.set_collect_stats(False)
 

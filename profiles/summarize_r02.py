@@ -60,29 +60,3 @@ if m("SQ_INSTS_VALU") and m("GRBM_GUI_ACTIVE"):
 json.dump({"kernel": needle, "kernel_trace_stats": stats, "derived": derived, "counters": counters, "bench_line": bench},
           sys.stdout, indent=1)
 print()
-# the small files bench.py reads: --emit <headline|streaming> <summary file name as it will be committed>
-if "--emit" in sys.argv:
-    leg, src = sys.argv[sys.argv.index("--emit") + 1], sys.argv[sys.argv.index("--emit") + 2]
-    here = os.path.dirname(os.path.abspath(__file__))
-    source = f"profiles/{src} (rocprofv3 --pmc passes of profiles/collect_r02.sh, mean over the timed kernel's dispatches; gfx950 FETCH_SIZE correction applied)"
-    if leg == "headline":
-        json.dump({"source": source, "bytes_per_launch": derived["hbm_bytes_per_launch"],
-                   "read_bytes_per_launch": derived["hbm_read_bytes_per_launch"],
-                   "write_bytes_per_launch": derived["hbm_write_bytes_per_launch"]},
-                  open(os.path.join(here, "r02_headline_traffic.json"), "w"), indent=1)
-        json.dump({"source": source, "SQ_INSTS_VALU_per_launch": m("SQ_INSTS_VALU"), "SQ_INSTS_SALU_per_launch": m("SQ_INSTS_SALU"),
-                   "SQ_WAVES_per_launch": m("SQ_WAVES"),
-                   "lanes_active_per_valu_instruction": derived.get("lanes_active_per_valu_instruction")},
-                  open(os.path.join(here, "r02_headline_valu.json"), "w"), indent=1)
-    else:
-        rs = bench["roofline_streaming"]
-        import re
-        tri = int(re.match(r"(\d+) distinct", rs["workload"]).group(1))
-        cell = float(re.search(r"grid cell ([0-9.]+)", rs["workload"]).group(1))
-        rec = {"source": source, "triangles": tri, "cell_size": cell, "bytes_per_launch": derived["hbm_bytes_per_launch"],
-               "read_bytes_per_launch": derived["hbm_read_bytes_per_launch"],
-               "write_bytes_per_launch": derived["hbm_write_bytes_per_launch"]}
-        for k in ("l2_hit_rate", "lanes_active_per_valu_instruction", "ta_busy_frac", "valu_issue_frac"):
-            if k in derived:
-                rec[k] = derived[k]
-        json.dump(rec, open(os.path.join(here, "r02_streaming_traffic.json"), "w"), indent=1)

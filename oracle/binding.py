@@ -51,11 +51,12 @@ class Params(C.Structure):
     _fields_ = [("finest_cell_size", C.c_float), ("max_objects_per_cell", C.c_uint32), ("max_dda_steps", C.c_uint32),
                 ("wgsl_compat", C.c_uint32), ("lod_cull", C.c_uint32), ("moving_box_count", C.c_uint32),
                 ("fov", C.c_float), ("light_direction", C.c_float * 3), ("shadow_offset", C.c_float),
-                ("collect_stats", C.c_uint32), ("skip_duplicate_triangles", C.c_uint32)]
+                ("collect_stats", C.c_uint32), ("skip_duplicate_triangles", C.c_uint32),
+                ("heavy_block_threshold", C.c_uint32)]  # the last two: the GPU library's own, nothing the oracle reads
 
     @classmethod
     def default(cls, **kw):
-        p = cls(16.0, 8192, 200, 0, 1, 3, 0.785398, (C.c_float * 3)(0.5, -1.0, 0.3), 0.001, 0, 1)
+        p = cls(16.0, 8192, 200, 0, 1, 3, 0.785398, (C.c_float * 3)(0.5, -1.0, 0.3), 0.001, 0, 1, 0)
         for k, v in kw.items():
             setattr(p, k, v)
         return p
@@ -81,10 +82,14 @@ class Shard(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("primary_hits", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("shadow_hits", C.c_uint64), ("cells_visited", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("box_tests", C.c_uint64)]
+                ("box_tests", C.c_uint64),
+                # rt_stats continues with counts of what the GPU library fetched; the oracle leaves them zero
+                ("cell_records_fetched", C.c_uint64), ("ref_records_fetched", C.c_uint64),
+                ("ref_records_staged", C.c_uint64), ("cell_records_uniform", C.c_uint64)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        """The counts of the reference's work (the part of rt_stats the oracle fills)."""
+        return {k: int(getattr(self, k)) for k, _ in self._fields_[:7]}
 
 
 class RenderOpts(C.Structure):

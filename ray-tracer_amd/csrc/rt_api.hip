@@ -445,11 +445,67 @@ bool wide_grid(const DevScene& s) {
     return ((uint64_t)s.n_refs + 1) * 48 > 0xFFFFFFFFull || (uint64_t)s.n_bordered * 8 > 0xFFFFFFFFull;
 }
 
+constexpr uint32_t PLAN_CAP_HEAVY = 1024;  // most 8x8 blocks a plan traces four lanes per ray: that many workgroups
+constexpr uint32_t PLAN_CAP_EARLY = 4096;  // most it moves to the front as they are: a quarter as many workgroups
+constexpr uint32_t PLAN_LEAD_WGS = PLAN_CAP_HEAVY + PLAN_CAP_EARLY / 4;  // lead every planned launch
+constexpr size_t PLAN_MAX_SLOTS = 8;       // (stream, frame shape) pairs remembered per context
+
+// The plan for this stream and frame shape, made on first use (which allocates: the entry point that must not allocate
+// never comes here). *plan stays null when there is none to be had; the caller then launches the plain kernel.
+int plan_for(rt_ctx* c, const ShardMap& m, const DevFrame& f, uint32_t n_blocks, bool shadow, rt_plan** plan) {
+    *plan = nullptr;
+    const uint32_t key[8] = {f.width, f.height, m.tile_w, m.tile_h, m.first, m.stride, m.n_local, shadow ? 1u : 0u};
+    rt_plan* hit = nullptr;
+    for (rt_plan* p : c->plans)
+        if (p->stream == c->stream && p->offsets == m.offsets && p->n_blocks == n_blocks && !memcmp(p->key, key, sizeof(key))) hit = p;
+    if (!hit) {
+        if (c->plans.size() < PLAN_MAX_SLOTS) {
+            rt_plan* fresh = new rt_plan;
+            hit = fresh;
+            c->plans.push_back(hit);
+        } else {  // the slot used longest ago; nothing may still be reading it
+            for (rt_plan* p : c->plans)
+                if (!hit || p->last_use < hit->last_use) hit = p;
+            RT_HIP(c, hipDeviceSynchronize());
+        }
+        hit->stream = c->stream;
+        memcpy(hit->key, key, sizeof(key));
+        hit->offsets = m.offsets;
+        hit->n_blocks = n_blocks;
+        hit->cur = 0;
+        const size_t bytes = BlockPlan::HEADER + ((size_t)PLAN_CAP_HEAVY + PLAN_CAP_EARLY) * sizeof(uint32_t) + n_blocks;
+        for (rt::DevBuf& b : hit->buf) {
+            RT_HIP(c, b.reserve(bytes));
+            RT_HIP(c, hipMemsetAsync(b.p, 0, bytes, c->stream));  // an empty plan: no block listed
+        }
+    }
+    hit->last_use = ++c->plan_clock;
+    c->last_plan = hit;
+    *plan = hit;
+    return RT_OK;
+}
+
+BlockPlan make_block_plan(const rt_plan* p, uint32_t threshold_us) {
+    BlockPlan b;
+    b.cur = static_cast<const uint8_t*>(p->buf[p->cur].p);
+    b.next = static_cast<uint8_t*>(p->buf[(p->cur + 1) % 3].p);
+    b.after = static_cast<uint8_t*>(p->buf[(p->cur + 2) % 3].p);
+    b.cap_heavy = PLAN_CAP_HEAVY;
+    b.cap_early = PLAN_CAP_EARLY;
+    b.bytes = (uint32_t)(BlockPlan::HEADER + ((size_t)PLAN_CAP_HEAVY + PLAN_CAP_EARLY) * sizeof(uint32_t) + p->n_blocks);
+    b.threshold = threshold_us < 40000000u ? threshold_us * 100u : 0xFFFFFFFFu;  // microseconds -> 10 ns ticks
+    b.threshold_early = b.threshold / 2;
+#ifdef RT_EXPERIMENTS
+    if (const char* e = getenv("RT_PLAN_EARLY_PCT")) b.threshold_early = (uint32_t)((uint64_t)b.threshold * (uint32_t)atoi(e) / 100u);
+#endif
+    return b;
+}
+
 // Kernel variants: WGSL (constant set), SHADOW / ANY, BOXES (scene has boxes), TEX (hits decided by a texture's
 // alpha). The counting build is the general one (with the box path); so is the build for grids of 4 GiB and more.
 template <bool WGSL, bool SHADOW>
-void launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* op,
-                    uint2* os) {
+int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* op,
+                   uint2* os, bool may_alloc) {
     unsigned long long* st = c->stats.as<unsigned long long>();
 #ifdef RT_EXPERIMENTS
     if (const char* v = getenv("RT_VARIANT")) {
@@ -457,7 +513,7 @@ void launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const De
             const int vn = atoi(v);
             if (vn >= 40 && vn < 60) {  // persistent waves: one wave per wave slot of the chip
                 void* q = nullptr;
-                if (hipGetSymbolAddress(&q, HIP_SYMBOL(rt::g_queue)) != hipSuccess) return;
+                if (hipGetSymbolAddress(&q, HIP_SYMBOL(rt::g_queue)) != hipSuccess) return RT_OK;
                 (void)hipMemsetAsync(q, 0, sizeof(uint32_t), c->stream);
                 const uint32_t n_waves = grid.x * 4;
                 switch (vn) {
@@ -467,14 +523,18 @@ void launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const De
                     case 54: hipLaunchKernelGGL((k_trace_primary_persist<54>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
                     default: hipLaunchKernelGGL((k_trace_primary_persist<50>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
                 }
-                return;
+                return RT_OK;
             }
-            if (vn == 70) {  // the 80-scalar-register build of the shipped kernel
-                hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os);
-                return;
+            if (vn == 80) {  // four lanes per ray, every block
+                hipLaunchKernelGGL(k_trace_primary_quad_all, dim3(grid.x * 4), dim3(256), 0, c->stream, s, f, m, op, os);
+                return RT_OK;
+            }
+            if (vn == 71) {  // the shipped kernel without a plan of expensive blocks
+                hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+                return RT_OK;
             }
             switch (vn) {
-#define RT_VAR(N) case N: hipLaunchKernelGGL((k_trace_primary_var<N>), dim3(grid.x * (256 / VarCfg<N>::threads)), dim3(VarCfg<N>::threads), 0, c->stream, s, f, m, op, os); return;
+#define RT_VAR(N) case N: hipLaunchKernelGGL((k_trace_primary_var<N>), dim3(grid.x * (256 / VarCfg<N>::threads)), dim3(VarCfg<N>::threads), 0, c->stream, s, f, m, op, os); return RT_OK;
                 RT_VARIANT_LIST
 #undef RT_VAR
             }
@@ -500,8 +560,20 @@ void launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const De
             hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
     } else if (s.nb != 0)
         hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
-    else
-        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+    else {
+        // triangles only, no counters: the kernel that keeps a plan of expensive pixel blocks, when it may
+        rt_plan* plan = nullptr;
+        if (may_alloc && c->params.heavy_block_threshold && (uint64_t)grid.x * 4 + PLAN_LEAD_WGS < 0x7FFFFFFFull)
+            if (int r = plan_for(c, m, f, grid.x * 4, SHADOW, &plan)) return r;
+        if (plan) {
+            const BlockPlan bp = make_block_plan(plan, c->params.heavy_block_threshold);
+            hipLaunchKernelGGL((k_trace_primary_planned<WGSL, SHADOW>), dim3(grid.x + PLAN_LEAD_WGS), dim3(256), 0, c->stream, s, f, m, bp, op, os);
+            plan->cur = (plan->cur + 1) % 3;
+        } else {
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        }
+    }
+    return RT_OK;
 }
 
 template <bool WGSL, bool ANY>
@@ -621,6 +693,7 @@ extern "C" void rt_default_params(rt_params* p) {
     p->shadow_offset = 0.001f;
     p->collect_stats = 0;
     p->skip_duplicate_triangles = 1;
+    p->heavy_block_threshold = 0;
 }
 
 extern "C" const char* rt_create_error(void) { return g_create_error.c_str(); }
@@ -695,6 +768,10 @@ extern "C" void rt_destroy(rt_ctx* c) {
     for (rt_table* t : c->tables) {
         t->buf.release();
         delete t;
+    }
+    for (rt_plan* p : c->plans) {
+        for (DevBuf& b : p->buf) b.release();
+        delete p;
     }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -895,6 +972,21 @@ extern "C" int rt_get_grid(rt_ctx* c, GridMetadata* meta, uint32_t* n_cells, uin
     return RT_OK;
 }
 
+extern "C" int rt_get_heavy_blocks(rt_ctx* c, uint32_t* n_heavy, uint32_t* n_early) {
+    if (int r = use(c)) return r;
+    if (!n_heavy) return fail(c, RT_ERR_INVALID, "rt_get_heavy_blocks: NULL argument");
+    *n_heavy = 0;
+    if (n_early) *n_early = 0;
+    if (!c->last_plan) return RT_OK;
+    const rt_plan* p = c->last_plan;
+    uint32_t head[64] = {};  // the plan the NEXT launch of that shape will use: its two list lengths
+    RT_HIP(c, hipMemcpyAsync(head, p->buf[p->cur].p, sizeof(head), hipMemcpyDeviceToHost, p->stream));
+    RT_HIP(c, hipStreamSynchronize(p->stream));
+    *n_heavy = head[0] < PLAN_CAP_HEAVY ? head[0] : PLAN_CAP_HEAVY;
+    if (n_early) *n_early = head[32] < PLAN_CAP_EARLY ? head[32] : PLAN_CAP_EARLY;
+    return RT_OK;
+}
+
 extern "C" int rt_get_build_path(rt_ctx* c, int* path) {
     if (int r = use(c)) return r;
     if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_get_build_path: no grid");
@@ -1003,17 +1095,14 @@ static int trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t width, ui
     const DevFrame f = make_frame(c, cam, width, height);
     const dim3 grid((uint32_t)blocks);
     const bool wgsl = c->params.wgsl_compat != 0;
-    if (out_shadow) {
-        if (wgsl)
-            launch_primary<true, true>(c, stats, grid, s, f, m, op, os);
-        else
-            launch_primary<false, true>(c, stats, grid, s, f, m, op, os);
-    } else {
-        if (wgsl)
-            launch_primary<true, false>(c, stats, grid, s, f, m, op, os);
-        else
-            launch_primary<false, false>(c, stats, grid, s, f, m, op, os);
-    }
+    int lr;
+    if (out_shadow)
+        lr = wgsl ? launch_primary<true, true>(c, stats, grid, s, f, m, op, os, !NOALLOC)
+                  : launch_primary<false, true>(c, stats, grid, s, f, m, op, os, !NOALLOC);
+    else
+        lr = wgsl ? launch_primary<true, false>(c, stats, grid, s, f, m, op, os, !NOALLOC)
+                  : launch_primary<false, false>(c, stats, grid, s, f, m, op, os, !NOALLOC);
+    if (lr) return lr;
     RT_HIP(c, hipGetLastError());
     if (host_p) RT_HIP(c, hipMemcpyAsync(out_primary, op, n_out * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
     if (host_s) RT_HIP(c, hipMemcpyAsync(out_shadow, os, n_out * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
@@ -1522,6 +1611,13 @@ extern "C" int rt_dbg_wave_times(rt_ctx* c, unsigned long long* out, size_t n) {
     if (int r = use(c)) return r;
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_wave_t), n * sizeof(unsigned long long)));
+    return RT_OK;
+}
+// development only: per-block cost as the planned kernel reported it
+extern "C" int rt_dbg_wave_chain(rt_ctx* c, uint32_t* out, size_t n) {
+    if (int r = use(c)) return r;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_wave_chain), n * sizeof(uint32_t)));
     return RT_OK;
 }
 #endif

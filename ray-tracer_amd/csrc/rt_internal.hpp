@@ -55,8 +55,26 @@ struct rt_table {
     rt::DevBuf buf;
 };
 
+// Plan of expensive pixel blocks (BlockPlan in rt_trace.hpp) for one stream and one frame shape: three buffers used
+// in rotation (read, written, cleared for the launch after), each holding two list lengths, the two block lists and a
+// class byte per 8x8 block.
+// Launches on one stream are ordered, so the plan a launch reads is complete; frames in flight on other streams have
+// plans of their own.
+struct rt_plan {
+    hipStream_t stream = nullptr;
+    uint32_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // width, height, tile_w, tile_h, first, stride, local tiles, shadow
+    const uint32_t* offsets = nullptr;
+    uint32_t n_blocks = 0;
+    rt::DevBuf buf[3];
+    int cur = 0;
+    unsigned long long last_use = 0;
+};
+
 struct rt_ctx {
     int device = 0;
+    std::vector<rt_plan*> plans;
+    unsigned long long plan_clock = 0;
+    rt_plan* last_plan = nullptr;  // the plan of the most recent planned launch
     std::vector<rt_table*> tables;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream in use (own_stream or the caller's)

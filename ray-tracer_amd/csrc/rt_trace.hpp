@@ -121,6 +121,7 @@ __device__ v2i llvm_struct_buffer_load_v2i32(v4i rsrc, int vindex, int voffset, 
 
 // Scalar buffer load (s_buffer_load_dwordx2): for an offset that is the same in every lane. Read-only use.
 __device__ v2i llvm_s_buffer_load_v2i32(v4i rsrc, int offset, int aux) __asm("llvm.amdgcn.s.buffer.load.v2i32");
+__device__ int llvm_s_buffer_load_i32(v4i rsrc, int offset, int aux) __asm("llvm.amdgcn.s.buffer.load.i32");
 
 __device__ inline v4i make_rsrc(const void* base, uint32_t stride, uint32_t num_records) {
     const uint64_t b = (uint64_t)base;
@@ -175,10 +176,24 @@ __device__ inline float4* wave_stage() {
 // the triangle test, before comparing distances; a discarded or a farther hit changes nothing either way.)
 // WIDE: the reference records or the cell array span 4 GiB or more. A buffer descriptor forms its byte offset
 // (index * stride) in 32 bits, so such arrays are read through plain 64-bit pointers instead.
-// X: development switch (0 in every shipped instantiation).
+// X: 0 = the loop below; TRACE_QUAD (5) = four lanes per ray, see there; other values: development builds only.
+constexpr int TRACE_QUAD = 5;
+
 template <bool WGSL, bool ANY, int STATS, bool BOXES, bool TEX = false, bool WIDE = false, int X = 0>
-__device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitRec& out, Counters& ctr) {
+__device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitRec& out, Counters& ctr, uint32_t quad_step = 1) {
     constexpr bool SKIP = STATS != 1;
+    // X == TRACE_QUAD: the instantiation that can run FOUR LANES PER RAY, chosen per wave at run time (quad_step = 4;
+    // with quad_step = 1 it is the ordinary loop). The four lanes of a quad (lanes 4r .. 4r+3) then carry the SAME ray
+    // and walk the grid in lockstep; a cell's candidate list is dealt to them (lane q tests entries q, q+4, ...), and
+    // after the list the quad agrees on one result: the smallest t, and among equal t the earliest list position -
+    // which is what scanning the whole list in order with a strict '<' yields (any-hit: the earliest accepted
+    // position). Every lane then holds the same closest hit again, so the four take the same decisions at every step.
+    // A cell's list costs a quarter of the dependent chain; the steps between cells are done four times over. For
+    // pixel blocks known to be expensive. quad_step is the same in every lane of the wave.
+    constexpr bool QCAP = X == TRACE_QUAD;
+    static_assert(!QCAP || (!BOXES && !TEX && !WIDE && STATS == 0), "four lanes per ray: plain triangle scenes only");
+    const uint32_t qstep = QCAP ? quad_step : 1u;
+    const uint32_t qlane = QCAP && quad_step != 1u ? (threadIdx.x & 3u) : 0u;
     float closest = 1e10f;
     uint32_t best_id = MISS, best_ref = MISS;
     const V3 d = rd.d, inv = rd.inv;
@@ -306,7 +321,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     // A cell's candidate list. Two records per trip, each loaded while the other is tested, so the record in
     // flight never has to be copied into the registers of the record under test. The load one past the list
     // stays inside the array (padded by one record) and its result is not used.
-    auto scan = [&](uint32_t r, uint32_t n) {
+    auto scan_list = [&](uint32_t r, uint32_t n) {
         if constexpr (X != 2) {
             // LDS staging. When every active lane of the wave is about to scan the SAME cell list (rays of an 8x8
             // pixel block mostly are in the same cell), the wave copies the list's records into LDS once - each
@@ -333,8 +348,13 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    for (uint32_t k = 0; k < cnt && !done; ++k)
-                        done = test(mine[3 * k], mine[3 * k + 1], mine[3 * k + 2], r0 + base + k);
+                    if (!QCAP || qstep == 1u) {  // the loop counter is the same in every lane: a scalar loop
+                        for (uint32_t k = 0; k < cnt && !done; ++k)
+                            done = test(mine[3 * k], mine[3 * k + 1], mine[3 * k + 2], r0 + base + k);
+                    } else {
+                        for (uint32_t k = qlane; k < cnt && !done; k += 4)
+                            done = test(mine[3 * k], mine[3 * k + 1], mine[3 * k + 2], r0 + base + k);
+                    }
                     __builtin_amdgcn_wave_barrier();  // the next piece may overwrite the buffer only after every lane is done
                     if (ANY && __builtin_amdgcn_ballot_w64(!done) == 0ull) break;
                 }
@@ -342,6 +362,22 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             }
         }
         const uint32_t r_end = r + n;
+        if constexpr (QCAP) {
+            // this lane's share of the list: r + q, r + q + step, ... (step 1: the whole list, as below). A look-ahead
+            // load past the list reads zeros: the buffer descriptor bounds it.
+            r += qlane;
+            if (r >= r_end) return;
+            float4 a0 = ref_quad(r, Q0{}), a1 = ref_quad(r, Q1{}), a2 = ref_quad(r, Q2{});
+            for (;;) {
+                const float4 b0 = ref_quad(r + qstep, Q0{}), b1 = ref_quad(r + qstep, Q1{}), b2 = ref_quad(r + qstep, Q2{});
+                if (test(a0, a1, a2, r)) break;
+                if ((r += qstep) >= r_end) break;
+                a0 = ref_quad(r + qstep, Q0{}), a1 = ref_quad(r + qstep, Q1{}), a2 = ref_quad(r + qstep, Q2{});
+                if (test(b0, b1, b2, r)) break;
+                if ((r += qstep) >= r_end) break;
+            }
+            return;
+        }
         float4 a0 = ref_quad(r, Q0{}), a1 = ref_quad(r, Q1{}), a2 = ref_quad(r, Q2{});
         if (STATS == 2) ctr.ref_recs++;
         for (;;) {
@@ -353,6 +389,26 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             if (STATS == 2) ctr.ref_recs++;
             if (test(b0, b1, b2, r)) break;
             if (++r == r_end) break;
+        }
+    };
+    auto scan = [&](uint32_t r, uint32_t n) {
+        scan_list(r, n);
+        if (QCAP && qstep != 1u) {
+            // the quad's four partial results -> one: lane ^ 1, then lane ^ 2 (quad permutes: no LDS, no waiting)
+#define RT_QUAD_MERGE(CTRL)                                                                                                  \
+    {                                                                                                                        \
+        const uint32_t t_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(closest), CTRL, 0xF, 0xF, false); \
+        const uint32_t ref_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best_ref, CTRL, 0xF, 0xF, false);               \
+        const uint32_t id_p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)best_id, CTRL, 0xF, 0xF, false);                 \
+        const float tp = __uint_as_float(t_p);                                                                               \
+        const bool take = ANY ? (ref_p < best_ref) : (tp < closest || (tp == closest && ref_p < best_ref));                  \
+        closest = take ? tp : closest;                                                                                       \
+        best_ref = take ? ref_p : best_ref;                                                                                  \
+        best_id = take ? id_p : best_id;                                                                                     \
+    }
+            RT_QUAD_MERGE(0xB1)  // quad_perm [1, 0, 3, 2]
+            RT_QUAD_MERGE(0x4E)  // quad_perm [2, 3, 0, 1]
+#undef RT_QUAD_MERGE
         }
     };
 
@@ -587,13 +643,167 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
     trace_primary_block<WGSL, SHADOW, STATS, BOXES, TEX, WIDE>(s, f, m, out_p, out_s, stats);
 }
 
-// The same kernel for triangle-only scenes without counters, held to 80 scalar registers: a CU admits eight 256-thread
-// workgroups only up to 80 (seven up to 96), and the general kernel holds 93. Eight scalars live in a vector register's
-// lanes instead (63 vector registers, still eight waves per SIMD).
+// Pixel blocks that are expensive: a plan made by one launch for the next one of the same frame shape.
+//
+// A frame's duration is not its work: the chip is full for the first two thirds of a launch, then drains for as long
+// again while a few hundred waves finish - 8x8 pixel blocks over the model's densest cells, whose rays walk hundreds
+// of candidates (one dependent chain per wave), and moderately expensive blocks that merely started late because they
+// lie at the bottom of the picture. Which blocks those are hardly changes from one frame of a camera path (or of an
+// animation) to the next, so every launch records how long each block's wave ran (the 100 MHz s_memrealtime clock:
+// two scalar reads per wave, nothing in the traversal loop) and sorts the block into one of three classes for the
+// next launch:
+//   heavy  (>= threshold):      traced with FOUR LANES PER RAY (trace_ray<TRACE_QUAD>: a workgroup per block, a 4x4
+//                               pixel quadrant per wave, candidate lists dealt to the four lanes of a ray), a quarter
+//                               of the chain per list, by the workgroups at the very front of the grid;
+//   early  (>= threshold / 2):  traced as ever, but by the workgroups that come next, so none of them starts late;
+//   others:                     in picture order, by the rest of the grid.
+// A wrong plan (first frame, camera cut) costs time, never correctness: every block is traced by exactly one wave or
+// workgroup, and both shapes give the same bits.
+struct BlockPlan {
+    // One buffer per plan: the two list lengths (each in 128 bytes of its own), then cap_heavy and cap_early block
+    // numbers (8x8 blocks, numbered like the plain kernel's waves), then one class byte per 8x8 block (0 = others).
+    // Three buffers rotate, so nothing needs clearing between launches.
+    const uint8_t* cur;  // the plan this launch follows
+    uint8_t* next;       // the plan it writes for the next launch; its list lengths are zero when the launch starts
+    uint8_t* after;      // the buffer of the launch after that: this launch zeroes its list lengths
+    uint32_t cap_heavy;  // most blocks the heavy list holds = workgroups that lead the grid
+    uint32_t cap_early;  // most blocks the early list holds (a multiple of four) = 4 x the workgroups that follow
+    uint32_t threshold;  // wave run time, in 10 ns ticks, from which a block is heavy
+    uint32_t threshold_early;  // ... from which it is early
+
+    uint32_t bytes;      // size of one buffer
+
+    static constexpr uint32_t HEADER = 256;
+    __device__ static uint32_t& word(uint8_t* b, size_t at) { return *reinterpret_cast<uint32_t*>(b + at); }
+    __device__ uint32_t at_heavy(uint32_t j) const { return HEADER + j * 4; }
+    __device__ uint32_t at_early(uint32_t j) const { return HEADER + (cap_heavy + j) * 4; }
+    __device__ uint32_t at_class(uint32_t gw) const { return HEADER + (cap_heavy + cap_early) * 4 + gw; }
+};
+
+// What a launch reads of its plan (every offset is the same in all lanes of the wave) goes through the scalar cache:
+// the vector memory path is where the traversal's loads queue, and a wave would wait there before it has begun.
+struct PlanReader {
+    v4i d;
+    __device__ explicit PlanReader(const BlockPlan& p) : d(make_rsrc(p.cur, 0, p.bytes)) {}
+    __device__ uint32_t at(uint32_t byte_offset) const { return (uint32_t)llvm_s_buffer_load_i32(d, (int)byte_offset, 0); }
+};
+
+// One lane reports what its block cost.
+__device__ inline void plan_block(const BlockPlan& p, uint32_t gw, uint32_t ticks) {
+    uint8_t cls = 0;
+    if (ticks >= p.threshold) {
+        const uint32_t j = atomicAdd(&BlockPlan::word(p.next, 0), 1u);
+        if (j < p.cap_heavy) {
+            BlockPlan::word(p.next, p.at_heavy(j)) = gw;
+            cls = 2;
+        }
+    }
+    if (cls == 0 && ticks >= p.threshold_early) {  // also where a full heavy list turned the block away
+        const uint32_t j = atomicAdd(&BlockPlan::word(p.next, 128), 1u);
+        if (j < p.cap_early) {
+            BlockPlan::word(p.next, p.at_early(j)) = gw;
+            cls = 1;
+        }
+    }
+    p.next[p.at_class(gw)] = cls;
+}
+
+#ifdef RT_EXPERIMENTS
+__device__ unsigned long long g_wave_t[2 * 65536];  // development builds: s_memrealtime (100 MHz) at wave start / end,
+__device__ uint32_t g_wave_chain[65536];            // and the cost a block reported (bits 30-31: its class)
+#endif
+
+// k_trace_primary for triangle-only scenes without counters (the common case), with the plan above. The grid is
+// cap_heavy workgroups for the heavy list, cap_early / 4 for the early list (those beyond a list's length exit at
+// once), then the plain kernel's 16x16-pixel workgroups. One traversal body serves both shapes (the lanes-per-ray count
+// is a run-time scalar): two bodies in one kernel need 76 vector registers, two kernels need two streams per frame in
+// flight, and the four hardware queues of a process are then shared between them and frames no longer overlap.
 template <bool WGSL, bool SHADOW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_trace_primary_lean(
-    DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p, uint2* __restrict__ out_s) {
-    trace_primary_block<WGSL, SHADOW, 0, false, false, false>(s, f, m, out_p, out_s, nullptr);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_trace_primary_planned(
+    DevScene s, DevFrame f, ShardMap m, BlockPlan p, uint2* __restrict__ out_p, uint2* __restrict__ out_s) {
+    const uint32_t t_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    // the wave's number inside the workgroup is the same in all its lanes: say so, and everything derived from it
+    // (the block number, its tile, the plan look-up) stays in scalar registers
+    const uint32_t lane = threadIdx.x & 63, w4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;  // 16x16 blocks per tile
+    const uint32_t blk_per_tile = blk_x * blk_y;
+    const uint32_t wg_early = p.cap_heavy, wg_rest = p.cap_heavy + p.cap_early / 4;
+    const bool quad = blockIdx.x < wg_early;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) BlockPlan::word(p.after, 0) = 0, BlockPlan::word(p.after, 128) = 0;
+    const PlanReader plan(p);
+    uint32_t gw;  // the 8x8 block this wave (or, four lanes per ray, this workgroup) traces
+    if (quad) {
+        if (blockIdx.x >= plan.at(0)) return;
+        gw = plan.at(p.at_heavy(blockIdx.x));
+    } else if (blockIdx.x < wg_rest) {
+        const uint32_t j = (blockIdx.x - wg_early) * 4 + w4;
+        if (j >= plan.at(128)) return;
+        gw = plan.at(p.at_early(j));
+    } else {
+        gw = (blockIdx.x - wg_rest) * 4 + w4;
+        // the class bytes of the workgroup's four blocks are one word; not zero: traced from a list
+        if (((plan.at(p.at_class(gw & ~3u)) >> (8 * w4)) & 0xFFu) != 0) return;
+    }
+    const uint32_t b16 = gw >> 2, g4 = gw & 3;
+    const uint32_t lt = b16 / blk_per_tile, blk = b16 % blk_per_tile;
+    if (lt >= m.n_local) return;
+    const uint32_t sub_x = (blk % blk_x) * 2 + (g4 & 1), sub_y = (blk / blk_x) * 2 + (g4 >> 1);
+    // four lanes per ray: wave = 4x4 quadrant, four lanes per pixel; else: wave = the 8x8 block, a lane per pixel
+    const uint32_t r = quad ? lane >> 2 : lane;
+    const uint32_t lx = sub_x * 8 + (quad ? (w4 & 1) * 4 + (r & 3) : (r & 7));
+    const uint32_t ly = sub_y * 8 + (quad ? (w4 >> 1) * 4 + (r >> 2) : (r >> 3));
+    const uint32_t qstep = quad ? 4u : 1u;
+    const uint32_t tile = shard_tile(m, lt);
+    const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
+    const bool in_tile = lx < m.tile_w && ly < m.tile_h;
+    const bool live = in_tile && px < f.width && py < f.height;
+
+    uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
+    Counters ctr{};
+    if (live) {
+        const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+        const V3 d = primary_dir(f, px, py);
+        const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
+        HitRec h;
+        if (trace_ray<WGSL, false, 0, false, false, false, TRACE_QUAD>(s, o, rd, h, ctr, qstep)) {
+            ph = make_uint2(h.id, __float_as_uint(h.t));
+            if (SHADOW) {
+                const V3 pos = o + d * h.t;
+                V3 n = hit_normal(s, h, pos);
+                if (dot(n, d) > 0.0f) n = neg(n);
+                const V3 so = pos + n * f.shadow_offset;
+                HitRec oh;
+                if (trace_ray<WGSL, true, 0, false, false, false, TRACE_QUAD>(s, so, f.shadow, oh, ctr, qstep))
+                    sh = make_uint2(oh.id, __float_as_uint(oh.t));
+            }
+        }
+    }
+    if (in_tile && (!quad || (lane & 3) == 0)) {
+        const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
+        out_p[oi] = ph;
+        if (SHADOW) out_s[oi] = sh;
+    }
+    // what this block cost, for the next launch's plan
+    const uint32_t ticks = (uint32_t)__builtin_amdgcn_s_memrealtime() - t_start;
+    if (quad) {
+        // the slowest of the four waves; one lane per ray it would have taken about three times as long: say so, or
+        // the block would leave the list again because the list made it fast
+        __shared__ uint32_t wg_ticks;
+        if (threadIdx.x == 0) wg_ticks = 0;
+        __syncthreads();
+        if (lane == 0) atomicMax(&wg_ticks, ticks);
+        __syncthreads();
+        if (threadIdx.x == 0) plan_block(p, gw, 3u * wg_ticks);
+    } else if (lane == 0) {
+        plan_block(p, gw, ticks);
+    }
+#ifdef RT_EXPERIMENTS
+    if (gw < 65536 && (quad ? threadIdx.x == 0 : lane == 0)) {
+        g_wave_t[2 * gw] = __builtin_amdgcn_s_memrealtime() - ticks;
+        g_wave_t[2 * gw + 1] = __builtin_amdgcn_s_memrealtime();
+        g_wave_chain[gw] = ticks | (quad ? 0x80000000u : blockIdx.x < wg_rest ? 0x40000000u : 0u);
+    }
+#endif
 }
 
 // Explicit ray list: one lane per ray.

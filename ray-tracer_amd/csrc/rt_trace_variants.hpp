@@ -23,7 +23,6 @@ __device__ inline bool trace_ray_x(const DevScene& s, V3 o, const RayDir& rd, Hi
     return trace_ray<false, ANY, 0, false, false, false, BODY>(s, o, rd, out, ctr);
 }
 
-__device__ unsigned long long g_wave_t[2 * 65536];  // s_memrealtime (100 MHz) at wave start / end
 
 template <int VARIANT>
 struct VarCfg {
@@ -78,6 +77,49 @@ __global__ __launch_bounds__(256) void k_trace_primary_persist(DevScene s, DevFr
 }
 
 RT_SGPR80(60)
+
+// Variant 80: every 8x8 pixel block by a workgroup of four waves, each wave a 4x4 quadrant with four lanes per ray
+// (trace_ray<X = 5>). The whole frame this way measures what the mode costs where it is NOT needed; a small frame over
+// the model's densest cells measures what it gains where it is.
+__global__ __launch_bounds__(256) void k_trace_primary_quad_all(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
+                                                                uint2* __restrict__ out_s) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t gw = blockIdx.x;  // the 8x8 block, numbered as the waves of the shipped kernel
+    const uint32_t w4 = gw & 3, b16 = gw >> 2;
+    const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;
+    const uint32_t blk_per_tile = blk_x * blk_y;
+    const uint32_t lt = b16 / blk_per_tile, blk = b16 % blk_per_tile;
+    if (lt >= m.n_local) return;
+    const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
+    const uint32_t r = lane >> 2;
+    const uint32_t lx = sub_x * 8 + (w & 1) * 4 + (r & 3), ly = sub_y * 8 + (w >> 1) * 4 + (r >> 2);
+    const uint32_t tile = shard_tile(m, lt);
+    const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
+    const bool in_tile = lx < m.tile_w && ly < m.tile_h;
+    const bool live = in_tile && px < f.width && py < f.height;
+    uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
+    Counters ctr{};
+    if (live) {
+        const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+        const V3 d = primary_dir(f, px, py);
+        HitRec h;
+        const RayDir rd = make_ray_dir<false>(d, s.cell_size, s.px, s.pxy);
+        if (trace_ray<false, false, 0, false, false, false, TRACE_QUAD>(s, o, rd, h, ctr, 4u)) {
+            ph = make_uint2(h.id, __float_as_uint(h.t));
+            const V3 pos = o + d * h.t;
+            V3 n = hit_normal(s, h, pos);
+            if (dot(n, d) > 0.0f) n = neg(n);
+            const V3 so = pos + n * f.shadow_offset;
+            HitRec oh;
+            if (trace_ray<false, true, 0, false, false, false, TRACE_QUAD>(s, so, f.shadow, oh, ctr, 4u)) sh = make_uint2(oh.id, __float_as_uint(oh.t));
+        }
+    }
+    if (in_tile && (lane & 3) == 0) {
+        const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
+        out_p[oi] = ph;
+        out_s[oi] = sh;
+    }
+}
 
 template <int VARIANT>
 __device__ inline void trace_block(const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* __restrict__ out_p,

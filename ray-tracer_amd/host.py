@@ -191,6 +191,13 @@ class TraceCore:
         self._ck(self._L.rt_get_grid(self._h, C.byref(meta), C.byref(nc), C.byref(nr)))
         return meta, nc.value, nr.value
 
+    def heavy_blocks(self):
+        """(heavy, early): 8x8 pixel blocks the last planned trace_primary launch marked for the next one - to be traced
+        four lanes per ray / to be started ahead of picture order."""
+        n, e = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.rt_get_heavy_blocks(self._h, C.byref(n), C.byref(e)))
+        return n.value, e.value
+
     def build_path(self):
         """0: general build, 1: rebuild with every size kept on the device, -1: grid supplied by the caller."""
         v = C.c_int()

@@ -46,7 +46,15 @@ def test_wire_struct_sizes(rt):
     # sizes asserted in include/rt_types.h (reference src/types.rs, src/grid.rs)
     assert C.sizeof(rt.CameraUniform) == 80 and C.sizeof(rt.GridMetadata) == 96 and C.sizeof(rt.RayDebugInfo) == 80
     assert rt.BOX_DTYPE.itemsize == 96 and rt.TRIANGLE_DTYPE.itemsize == 80 and rt.HIT_DTYPE.itemsize == 8
-    assert C.sizeof(rt.RtStats) == 88 and C.sizeof(rt.RtShard) == 24 and C.sizeof(rt.RtParams) == 52
+    assert C.sizeof(rt.RtStats) == 88 and C.sizeof(rt.RtShard) == 24 and C.sizeof(rt.RtParams) == 56
+
+
+def test_oracle_binding_shares_the_header_structs(rt, ob):
+    """The oracle is compiled against the same rt_params / rt_stats / rt_shard as the library (oracle.h includes the
+    public header for its types), so its Python binding has to lay them out the same way, field for field."""
+    for mine, theirs in ((ob.Params, rt.RtParams), (ob.Stats, rt.RtStats), (ob.Shard, rt.RtShard), (ob.CameraUniform, rt.CameraUniform)):
+        assert C.sizeof(mine) == C.sizeof(theirs), mine
+        assert [(n, getattr(mine, n).offset) for n, _ in mine._fields_] == [(n, getattr(theirs, n).offset) for n, _ in theirs._fields_], mine
 
 
 def test_default_params_are_the_reference_constants(rt):

@@ -62,7 +62,9 @@ def test_random_scenes(rt, ob):
         cell = float(rng.choice([16.0, 16.0, 4.0, 1.0])) * (ext / 40.0 if rng.random() < 0.5 else 1.0)
         cap = int(rng.choice([8192, 8192, 6]))
         mats = alpha_materials(ob) if rng.random() < 0.5 else None
-        core = rt.TraceCore(0, rt.default_params(**kw))
+        # expensive-block plan: off, the default, or so low that every block with a candidate is traced four lanes per ray
+        heavy = int(rng.choice([0, 64, 1, 3]))
+        core = rt.TraceCore(0, rt.default_params(heavy_block_threshold=heavy, **kw))
         core.set_scene(boxes, tris)
         core.set_materials(mats)
         try:
@@ -92,6 +94,10 @@ def test_random_scenes(rt, ob):
             rays += st["rays"]
             mism += bad
             assert bad == 0, f"trial {trial} view {view}: {bad} records differ ({kw}, cell {cell}, cap {cap})"
+            for again in range(2):  # the same frame again: now with the plan the first launch made
+                p2, s2 = core.trace_primary(cam, w, h)
+                assert p2.tobytes() == p.tobytes() and s2.tobytes() == s.tobytes(), \
+                    f"trial {trial} view {view}: repeat {again} differs (heavy_block_threshold {heavy}, {core.heavy_blocks()} blocks listed)"
             bounces, shadows = int(rng.choice([1, 3, 8])), bool(rng.random() < 0.5)
             img = core.render(cam, w, h, max_bounces=bounces, shadows=shadows)
             oimg, _ = ob.render(scene, oc, w, h, params=params, max_bounces=bounces, shadows=shadows)

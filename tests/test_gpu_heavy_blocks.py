@@ -1,0 +1,98 @@
+"""The plan of expensive pixel blocks (rt_params.heavy_block_threshold, a wave run time in microseconds): blocks one
+launch finds expensive are traced four lanes per ray, or just earlier, by the next launch of the same frame shape on
+the same stream. Whatever the plan says - empty, stale, every block listed - the records must equal the oracle's bit
+for bit; the reference has one lane per pixel and no such
+notion (raytracer_unified.wgsl:624-721), so the oracle knows nothing of it."""
+import math
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_hits_equal, ocam, oparams
+
+pytestmark = pytest.mark.gpu
+
+
+def frames_equal_oracle(core, ob, scene, cam, w, h, n=3, shard=None, what=""):
+    oshard = ob.Shard(shard.tile_w, shard.tile_h, shard.first, shard.stride, shard.owner_list()) if shard is not None else None
+    op, os_, _ = ob.trace_primary(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params), shard=oshard, n_threads=8)
+    listed = []
+    for k in range(n):
+        p, s = core.trace_primary(cam, w, h, shard=shard)
+        assert_hits_equal(p, op, f"{what} frame {k} primary")
+        assert_hits_equal(s, os_, f"{what} frame {k} shadow")
+        listed.append(core.heavy_blocks())
+    return listed, op
+
+
+@pytest.mark.parametrize("threshold", [1, 2, 8, 64])
+def test_car_frames_with_a_plan(rt, ob, car_xyz9, threshold):
+    core = rt.TraceCore(0, rt.default_params(heavy_block_threshold=threshold))
+    try:
+        tris = rt.triangles_from_xyz9(car_xyz9)
+        core.set_scene(None, tris)
+        core.build_grid()
+        scene = ob.Scene(None, ob.triangles_from_xyz9(car_xyz9))
+        w, h = 480, 270
+        cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+        listed, op = frames_equal_oracle(core, ob, scene, cam, w, h, what=f"car threshold {threshold}")
+        heavy, early = zip(*listed)
+        if threshold == 1:  # a microsecond: every block that traced anything is heavy
+            assert min(heavy) > 300 and max(early) <= 2040 - min(heavy), listed
+        # a camera cut: the plan is stale for one frame
+        cam2 = rt.Camera((150, 120, 250), 3.4, -0.3).to_uniform(0.0, float(h))
+        frames_equal_oracle(core, ob, scene, cam2, w, h, n=2, what="after a camera cut")
+        # another frame shape and a shard get plans of their own; more shapes than the context remembers recycle one
+        for k, (w2, h2) in enumerate([(96, 54), (333, 187), (64, 36), (200, 120), (128, 72), (160, 90), (100, 60), (90, 50), (80, 40)]):
+            cam3 = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h2))
+            frames_equal_oracle(core, ob, scene, cam3, w2, h2, n=2, what=f"shape {w2}x{h2}")
+        sh = rt.RtShard(32, 16, 1, 3)
+        frames_equal_oracle(core, ob, scene, cam, w, h, n=3, shard=sh, what="shard")
+        frames_equal_oracle(core, ob, scene, cam, w, h, n=2, what="back to the whole frame")
+    finally:
+        core.close()
+
+
+def test_exact_ties_inside_a_list_are_resolved_by_list_order(rt, ob):
+    """30 000 benchmark triangles with every list entry tested: each hit is an exact three-way tie inside one list, and
+    the three copies are dealt to different lanes of a quad. The earliest list position must win, as in a scan in order."""
+    core = rt.TraceCore(0, rt.default_params(heavy_block_threshold=1, skip_duplicate_triangles=0))
+    try:
+        tris = ob.generate_test_triangles(30000)
+        core.set_scene(None, tris)
+        core.build_grid()
+        scene = ob.Scene(None, tris)
+        for pose in (rt.Camera((0, 0, 150), math.pi, 0.0), rt.Camera((3.0, -2.0, 49.0), math.pi + 0.2, -0.1)):
+            cam = pose.to_uniform(0.0, 54.0)
+            listed, op = frames_equal_oracle(core, ob, scene, cam, 96, 54, what="ties")
+            hit = op["id"] != ob.MISS
+            assert hit.sum() > 100 and np.all(op["id"][hit] < 10000) and listed[1][0] > 0, listed
+    finally:
+        core.close()
+
+
+def test_plans_are_per_stream(rt, ob, phoenix_xyz9):
+    """Frames in flight on two streams, different cameras: each stream keeps the plan of ITS last frame."""
+    import torch
+    core = rt.TraceCore(0, rt.default_params(heavy_block_threshold=4))
+    try:
+        core.set_scene(None, rt.triangles_from_xyz9(phoenix_xyz9))
+        core.build_grid()
+        scene = ob.Scene(None, ob.triangles_from_xyz9(phoenix_xyz9))
+        w, h = 320, 180
+        cams = [rt.Camera((-300, 250, 600), 2.7, -0.2).to_uniform(0.0, float(h)), rt.Camera((100, 300, 500), 3.3, -0.4).to_uniform(0.0, float(h))]
+        want = [ob.trace_primary(scene, ocam(ob, c), w, h, params=oparams(ob, core.params), n_threads=8) for c in cams]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        bufs = [[torch.empty((w * h, 2), dtype=torch.int32, device="cuda") for _ in range(2)] for _ in range(2)]
+        for k in range(8):
+            j = k % 2
+            core.set_stream(streams[j].cuda_stream)
+            core.trace_primary(cams[j], w, h, out_primary=bufs[j][0], out_shadow=bufs[j][1])
+            if k >= 6:  # the last frame of each stream
+                core.sync()
+                assert_hits_equal(bufs[j][0].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want[j][0], f"stream {j} primary")
+                assert_hits_equal(bufs[j][1].cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want[j][1], f"stream {j} shadow")
+        core.set_stream(None)
+        assert (want[0][0]["id"] != ob.MISS).sum() > 1000
+    finally:
+        core.close()

@@ -16,8 +16,8 @@ import ray_tracer_amd as rt  # noqa: E402
 
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2]
 rounds, steps = 7, 50
-W, H = 1920, 1080
-core = rt.TraceCore(0)
+W, H = (int(x) for x in os.environ.get("RT_SIZE", "1920x1080").split("x"))
+core = rt.TraceCore(0, rt.default_params(heavy_block_threshold=int(os.environ.get("RT_HEAVY", "64"))))
 MODEL = os.environ.get("RT_MODEL", "car")
 CELL = 0.0
 if MODEL.startswith("stream"):  # bench.py's streaming leg: n distinct random triangles, camera inside the volume
@@ -110,6 +110,7 @@ for r in range(rounds):
             core.timer_begin()
             frames(steps)
             times[v].append(core.timer_end() / steps * 1e3)
+print(f"blocks listed (four lanes per ray, early): {core.heavy_blocks()}")
 for v in variants:
     t = np.array(times[v])
     print(f"variant {v}: median {np.median(t):7.1f} us  min {t.min():7.1f} us")

@@ -84,9 +84,11 @@ typedef struct rt_params {
     uint32_t heavy_block_threshold; /* 0 = off. A wave run time in microseconds (64 is a good start). When set,
                                          rt_trace_primary on triangle-only scenes remembers, per stream and frame
                                          shape, how long each 8x8 pixel block's wave ran in the last frame. Blocks at
-                                         or above this run time are traced with four lanes per ray by the workgroups
+                                         or above a threshold are traced with four lanes per ray by the workgroups
                                          that start first, blocks above half of it are started right after them, the
-                                         rest follows in picture order. The same answers bit for bit. For frames
+                                         rest follows in picture order. The threshold starts at this value and never
+                                         drops below it; from frame to frame the library raises or lowers it so that a
+                                         few hundred blocks are listed. The same answers bit for bit. For frames
                                          that wait for a few dense spots of the model (a frame of the animated phoenix:
                                          168 -> 77 us); a frame whose cost is spread evenly gains nothing and pays
                                          about 8 % for the bookkeeping. No reference counterpart */
@@ -188,9 +190,10 @@ int rt_build_grid(rt_ctx* ctx, float cell_size, uint32_t max_per_cell, int mode)
 
 /* What the most recent rt_trace_primary launch that keeps a plan (params.heavy_block_threshold) decided for the next
  * launch of the same frame shape on the same stream: n_heavy 8x8 pixel blocks to be traced four lanes per ray, n_early
- * (may be NULL) to be started ahead of picture order as they are. Waits for that stream. Zeros when no such launch has
- * happened. No reference counterpart. */
-int rt_get_heavy_blocks(rt_ctx* ctx, uint32_t* n_heavy, uint32_t* n_early);
+ * to be started ahead of picture order as they are, and the run time (microseconds) that launch will call heavy. The
+ * last two may be NULL. Waits for that stream. Zeros (and the parameter) when no such launch has happened. No
+ * reference counterpart. */
+int rt_get_heavy_blocks(rt_ctx* ctx, uint32_t* n_heavy, uint32_t* n_early, uint32_t* threshold_us);
 
 /* How the current grid was made: 0 = rt_build_grid's general path (sizes read back by the host between passes,
  * duplicate search, any scene), 1 = its rebuild path for scenes of up to 65 536 objects whose grid has been built

@@ -151,7 +151,7 @@ PROTOTYPES = {
     "rt_render_frames": (_I, [_VP, _VP, _U32, _U32, _U32, C.POINTER(RtShard), C.POINTER(RtRenderOpts), _VP]),
     "rt_default_render_opts": (None, [C.POINTER(RtRenderOpts)]),
     "rt_set_materials": (_I, [_VP, _VP, _U32]),
-    "rt_get_heavy_blocks": (_I, [_VP, C.POINTER(_U32), C.POINTER(_U32)]),
+    "rt_get_heavy_blocks": (_I, [_VP, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
     "rt_get_build_path": (_I, [_VP, C.POINTER(_I)]),
     "rt_get_trace_refs": (_I, [_VP, C.POINTER(C.c_uint32)]),
     "rt_set_textures": (_I, [_VP, _VP, _U32]),

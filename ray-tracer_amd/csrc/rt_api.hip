@@ -494,10 +494,6 @@ BlockPlan make_block_plan(const rt_plan* p, uint32_t threshold_us) {
     b.cap_early = PLAN_CAP_EARLY;
     b.bytes = (uint32_t)(BlockPlan::HEADER + ((size_t)PLAN_CAP_HEAVY + PLAN_CAP_EARLY) * sizeof(uint32_t) + p->n_blocks);
     b.threshold = threshold_us < 40000000u ? threshold_us * 100u : 0xFFFFFFFFu;  // microseconds -> 10 ns ticks
-    b.threshold_early = b.threshold / 2;
-#ifdef RT_EXPERIMENTS
-    if (const char* e = getenv("RT_PLAN_EARLY_PCT")) b.threshold_early = (uint32_t)((uint64_t)b.threshold * (uint32_t)atoi(e) / 100u);
-#endif
     return b;
 }
 
@@ -972,18 +968,20 @@ extern "C" int rt_get_grid(rt_ctx* c, GridMetadata* meta, uint32_t* n_cells, uin
     return RT_OK;
 }
 
-extern "C" int rt_get_heavy_blocks(rt_ctx* c, uint32_t* n_heavy, uint32_t* n_early) {
+extern "C" int rt_get_heavy_blocks(rt_ctx* c, uint32_t* n_heavy, uint32_t* n_early, uint32_t* threshold_us) {
     if (int r = use(c)) return r;
     if (!n_heavy) return fail(c, RT_ERR_INVALID, "rt_get_heavy_blocks: NULL argument");
     *n_heavy = 0;
     if (n_early) *n_early = 0;
+    if (threshold_us) *threshold_us = c->params.heavy_block_threshold;
     if (!c->last_plan) return RT_OK;
     const rt_plan* p = c->last_plan;
-    uint32_t head[64] = {};  // the plan the NEXT launch of that shape will use: its two list lengths
+    uint32_t head[64] = {};  // the plan the NEXT launch of that shape will use: its two list lengths, its threshold
     RT_HIP(c, hipMemcpyAsync(head, p->buf[p->cur].p, sizeof(head), hipMemcpyDeviceToHost, p->stream));
     RT_HIP(c, hipStreamSynchronize(p->stream));
     *n_heavy = head[0] < PLAN_CAP_HEAVY ? head[0] : PLAN_CAP_HEAVY;
     if (n_early) *n_early = head[32] < PLAN_CAP_EARLY ? head[32] : PLAN_CAP_EARLY;
+    if (threshold_us) *threshold_us = (head[1] > c->params.heavy_block_threshold * 100u ? head[1] : c->params.heavy_block_threshold * 100u) / 100u;
     return RT_OK;
 }
 

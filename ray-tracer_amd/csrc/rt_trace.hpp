@@ -660,7 +660,8 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
 // A wrong plan (first frame, camera cut) costs time, never correctness: every block is traced by exactly one wave or
 // workgroup, and both shapes give the same bits.
 struct BlockPlan {
-    // One buffer per plan: the two list lengths (each in 128 bytes of its own), then cap_heavy and cap_early block
+    // One buffer per plan: the two list lengths (each in 128 bytes of its own; words 1 and 2: the threshold
+    // the launch that follows this plan uses, and the one the lists were made with), then cap_heavy and cap_early block
     // numbers (8x8 blocks, numbered like the plain kernel's waves), then one class byte per 8x8 block (0 = others).
     // Three buffers rotate, so nothing needs clearing between launches.
     const uint8_t* cur;  // the plan this launch follows
@@ -668,8 +669,7 @@ struct BlockPlan {
     uint8_t* after;      // the buffer of the launch after that: this launch zeroes its list lengths
     uint32_t cap_heavy;  // most blocks the heavy list holds = workgroups that lead the grid
     uint32_t cap_early;  // most blocks the early list holds (a multiple of four) = 4 x the workgroups that follow
-    uint32_t threshold;  // wave run time, in 10 ns ticks, from which a block is heavy
-    uint32_t threshold_early;  // ... from which it is early
+    uint32_t threshold;  // wave run time, in 10 ns ticks, below which no block is heavy (see plan_threshold)
 
     uint32_t bytes;      // size of one buffer
 
@@ -688,17 +688,17 @@ struct PlanReader {
     __device__ uint32_t at(uint32_t byte_offset) const { return (uint32_t)llvm_s_buffer_load_i32(d, (int)byte_offset, 0); }
 };
 
-// One lane reports what its block cost.
-__device__ inline void plan_block(const BlockPlan& p, uint32_t gw, uint32_t ticks) {
+// One lane reports what its block cost. threshold: the launch's (see plan_threshold).
+__device__ inline void plan_block(const BlockPlan& p, uint32_t gw, uint32_t ticks, uint32_t threshold) {
     uint8_t cls = 0;
-    if (ticks >= p.threshold) {
+    if (ticks >= threshold) {
         const uint32_t j = atomicAdd(&BlockPlan::word(p.next, 0), 1u);
         if (j < p.cap_heavy) {
             BlockPlan::word(p.next, p.at_heavy(j)) = gw;
             cls = 2;
         }
     }
-    if (cls == 0 && ticks >= p.threshold_early) {  // also where a full heavy list turned the block away
+    if (cls == 0 && ticks >= threshold / 2) {  // also where a full heavy list turned the block away
         const uint32_t j = atomicAdd(&BlockPlan::word(p.next, 128), 1u);
         if (j < p.cap_early) {
             BlockPlan::word(p.next, p.at_early(j)) = gw;
@@ -706,6 +706,35 @@ __device__ inline void plan_block(const BlockPlan& p, uint32_t gw, uint32_t tick
         }
     }
     p.next[p.at_class(gw)] = cls;
+}
+
+// The run time from which this launch calls a block heavy: the caller's threshold to begin with, then whatever the
+// launches before have steered it to (word 1 of the plan a launch follows). Four lanes per ray pay for a few hundred
+// blocks, the ones a frame waits for; which run time singles those out depends on the scene and on how many frames
+// are in flight, so every launch looks at the length of the list it was given and moves the threshold for the next
+// one: up by a quarter above PLAN_MANY blocks (doubled when the list was full), down by a sixteenth below PLAN_FEW,
+// never below the caller's. The list a launch sees was made with the threshold of the launch before, which is kept
+// beside it (word 2), and the correction starts from THAT value: even and odd launches steer themselves apart, and
+// neither reacts to a list its own threshold did not make.
+constexpr uint32_t PLAN_MANY = 512, PLAN_FEW = 128;
+__device__ inline uint32_t plan_threshold(const BlockPlan& p, const PlanReader& plan) {
+    const uint32_t steered = plan.at(4);
+    return steered > p.threshold ? steered : p.threshold;
+}
+__device__ inline void steer_plan(const BlockPlan& p, const PlanReader& plan) {  // one thread of the launch
+    BlockPlan::word(p.after, 0) = 0;
+    BlockPlan::word(p.after, 128) = 0;
+    // the list this launch follows, and the threshold it was made with (word 2; the launch before wrote both)
+    const uint32_t n = plan.at(0), made_with = plan.at(8);
+    uint32_t t = made_with > p.threshold ? made_with : p.threshold;
+    if (n >= p.cap_heavy)
+        t = t < 0x40000000u ? 2 * t : t;
+    else if (n > PLAN_MANY)
+        t = t < 0x60000000u ? t + t / 4 : t;
+    else if (n < PLAN_FEW)
+        t -= t / 16;
+    BlockPlan::word(p.next, 4) = t;  // for the next launch; plan_threshold() keeps it at or above the caller's
+    BlockPlan::word(p.next, 8) = plan_threshold(p, plan);  // what this launch makes the next list with
 }
 
 #ifdef RT_EXPERIMENTS
@@ -729,8 +758,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_tr
     const uint32_t blk_per_tile = blk_x * blk_y;
     const uint32_t wg_early = p.cap_heavy, wg_rest = p.cap_heavy + p.cap_early / 4;
     const bool quad = blockIdx.x < wg_early;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) BlockPlan::word(p.after, 0) = 0, BlockPlan::word(p.after, 128) = 0;
     const PlanReader plan(p);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) steer_plan(p, plan);
     uint32_t gw;  // the 8x8 block this wave (or, four lanes per ray, this workgroup) traces
     if (quad) {
         if (blockIdx.x >= plan.at(0)) return;
@@ -793,9 +822,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_tr
         __syncthreads();
         if (lane == 0) atomicMax(&wg_ticks, ticks);
         __syncthreads();
-        if (threadIdx.x == 0) plan_block(p, gw, 3u * wg_ticks);
+        if (threadIdx.x == 0) plan_block(p, gw, 3u * wg_ticks, plan_threshold(p, plan));
     } else if (lane == 0) {
-        plan_block(p, gw, ticks);
+        plan_block(p, gw, ticks, plan_threshold(p, plan));
     }
 #ifdef RT_EXPERIMENTS
     if (gw < 65536 && (quad ? threadIdx.x == 0 : lane == 0)) {

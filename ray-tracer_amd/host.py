@@ -194,9 +194,13 @@ class TraceCore:
     def heavy_blocks(self):
         """(heavy, early): 8x8 pixel blocks the last planned trace_primary launch marked for the next one - to be traced
         four lanes per ray / to be started ahead of picture order."""
-        n, e = C.c_uint32(), C.c_uint32()
-        self._ck(self._L.rt_get_heavy_blocks(self._h, C.byref(n), C.byref(e)))
-        return n.value, e.value
+        return self.heavy_plan()[:2]
+
+    def heavy_plan(self):
+        """(heavy, early, threshold_us): heavy_blocks() and the run time the next launch will call heavy."""
+        n, e, t = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self._L.rt_get_heavy_blocks(self._h, C.byref(n), C.byref(e), C.byref(t)))
+        return n.value, e.value, t.value
 
     def build_path(self):
         """0: general build, 1: rebuild with every size kept on the device, -1: grid supplied by the caller."""

@@ -233,16 +233,17 @@ def bvh(core):
              grid_cell=cell, grid_trace_ms=gms, grid_Mrays_per_s=len(o) / gms / 1e3, grid_hits=int((hits[:, 0] != -1).sum()))
 
 
-def animated_skinned(n_ctx=2):
+def animated_skinned(n_ctx=2, heavy=0):
     """The bundled animated model with its own skeleton animation: per frame 89 joint matrices go to the GPU
-    (5.7 KB), the skinning kernel writes the vertex array, the binning pass reads it, the frame is traced."""
+    (5.7 KB), the skinning kernel writes the vertex array, the binning pass reads it, the frame is traced.
+    heavy: rt_params.heavy_block_threshold (microseconds; 0 = no plan of expensive pixel blocks)."""
     from ray_tracer_amd.animation import SkinnedModel
     w, h = 1920, 1080
     model = SkinnedModel(os.path.join(ROOT, "tests", "golden", "phoenix_skin.npz"))
     mats = [model.joint_matrices(model.duration * f / 120) for f in range(120)]
     cores = []
     for _ in range(n_ctx):
-        c = rt.TraceCore(0)
+        c = rt.TraceCore(0, rt.default_params(heavy_block_threshold=heavy))
         c.set_scene(None, rt.triangles_from_xyz9(model.bind_pose_triangles()))
         c.set_skin(model.positions, model.joints, model.weights, model.tri_indices)
         cores.append(c)
@@ -266,7 +267,8 @@ def animated_skinned(n_ctx=2):
     run(False)
     ms = (time.perf_counter() - t0) * 1e3 / len(mats)
     emit(config="animated model, skeleton animation skinned on the GPU, 1920x1080 primary+shadow, per-frame rebuild",
-         contexts=n_ctx, triangles=len(model.tri_indices), joints=len(mats[0]), frames=len(mats), frame_ms=ms,
+         contexts=n_ctx, heavy_block_threshold_us=heavy, plan_heavy_early_threshold_us=cores[0].heavy_plan(),
+         triangles=len(model.tri_indices), joints=len(mats[0]), frames=len(mats), frame_ms=ms,
          rays_sampled=hits, Mrays_per_s_with_skinning_and_rebuild=float(np.mean(hits)) / ms / 1e3)
     for c in cores:
         c.close()
@@ -283,8 +285,9 @@ if __name__ == "__main__":
     if "animated" in what:
         animated(core)
         animated_pipelined(2)
-        animated_skinned(1)
-        animated_skinned(2)
+        for heavy in [int(v) for v in os.environ.get("RT_HEAVY_LIST", "0,64").split(",")]:
+            animated_skinned(1, heavy)
+            animated_skinned(2, heavy)
     if "bvh" in what:
         bvh(core)
     if "rays" in what:

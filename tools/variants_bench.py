@@ -110,7 +110,7 @@ for r in range(rounds):
             core.timer_begin()
             frames(steps)
             times[v].append(core.timer_end() / steps * 1e3)
-print(f"blocks listed (four lanes per ray, early): {core.heavy_blocks()}")
+print(f"plan (four lanes per ray, early, threshold us): {core.heavy_plan()}")
 for v in variants:
     t = np.array(times[v])
     print(f"variant {v}: median {np.median(t):7.1f} us  min {t.min():7.1f} us")

@@ -140,7 +140,7 @@ def streaming_leg(rt, dev, steps, warmup):
     mbytes = moved_bytes(mov, w * h)
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": None, "kernel": "k_trace_primary<shadow>", "kernel_ms": kernel_ms, "launches": steps,
+           "traffic": None, "kernel": "k_trace_primary_lean<shadow>", "kernel_ms": kernel_ms, "launches": steps,
            "workload": f"{n} distinct random triangles (seed 1) in a 100-unit cube, grid cell {cell:.4f} ({list(meta.fine_dims)} cells, "
                        f"{n_refs} references = {48 * core.trace_refs() / 1e9:.2f} GB of reference records), {w}x{h} primary + "
                        "shadow rays, camera (0,0,75) looking down -z (every primary ray enters the grid)",
@@ -468,13 +468,13 @@ def main():
                                     f"{GROUP} frames, RGB8, assembled to RGBA8, no collective")
         if multi and base_ms:
             out["speedup_vs_scaling_base"] = base_ms / ms_per_step
-        out["timed_kernel"] = ("k_trace_primary<shadow>: rt_hit records" if not multi else
+        out["timed_kernel"] = ("k_trace_primary_lean<shadow>: rt_hit records" if not multi else
                                "k_render<single bounce, shadow term>: RGB8 picture, rt_gather_frames (RCCL), rt_assemble_frames")
         if not multi:
             abytes = algorithmic_bytes(stats)
             mbytes = moved_bytes(moved, WIDTH * HEIGHT)
             frame_s = elapsed / args.steps
-            roof = {"kernel": "k_trace_primary<shadow>", "kernel_ms": kernel_ms, "concurrent_launches": FRAMES_IN_FLIGHT,
+            roof = {"kernel": "k_trace_primary_lean<shadow>", "kernel_ms": kernel_ms, "concurrent_launches": FRAMES_IN_FLIGHT,
                     "single_frame_us": single_us,
                     "algorithmic_bytes_per_launch": abytes, "algorithmic_GBps": abytes / frame_s / 1e9,
                     "cells_visited": stats["cells_visited"], "tri_tests": stats["tri_tests"],

@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-needle = sys.argv[2] if len(sys.argv) > 2 else "k_trace_primary<false, true, 0,"
+needle = sys.argv[2] if len(sys.argv) > 2 else "k_trace_primary_lean<false, true>"
 counters = {}
 for path in sorted(glob.glob(f"{root}/*/**/*counter_collection.csv", recursive=True)):
     acc = defaultdict(lambda: defaultdict(float))  # counter -> dispatch -> value

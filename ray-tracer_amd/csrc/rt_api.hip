@@ -526,6 +526,10 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
                 return RT_OK;
             }
             if (vn == 71) {  // the shipped kernel without a plan of expensive blocks
+                hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os);
+                return RT_OK;
+            }
+            if (vn == 73) {  // the general kernel's instantiation for the same scenes: 86 scalar registers, seven waves per SIMD
                 hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
                 return RT_OK;
             }
@@ -566,7 +570,7 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
             hipLaunchKernelGGL((k_trace_primary_planned<WGSL, SHADOW>), dim3(grid.x + PLAN_LEAD_WGS), dim3(256), 0, c->stream, s, f, m, bp, op, os);
             plan->cur = (plan->cur + 1) % 3;
         } else {
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+            hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os);
         }
     }
     return RT_OK;

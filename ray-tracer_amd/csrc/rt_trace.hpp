@@ -587,7 +587,63 @@ __device__ inline void flush_stats(unsigned long long* stats, unsigned long long
 // different XCDs at the same time: cheap (sky) and expensive (dense geometry) image regions are spread
 // evenly over the chip. (Giving each XCD one contiguous band of the image instead left most XCDs idle
 // behind the one that owned the geometry: 30 % average occupancy on the headline frame.)
-template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX, bool WIDE>
+// The first two arguments of the primary-ray kernels as the kernel-argument segment lays them out.
+struct PrimaryArgs {
+    DevScene s;
+    DevFrame f;
+    ShardMap m;
+    uint2* out_p;
+    uint2* out_s;
+};
+
+// A word / a pointer of the kernel-argument segment, read where it is needed (see late_shadow_dir).
+__device__ inline uint32_t late_arg_u32(uint32_t byte_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) uint8_t* KernArg;
+    KernArg base = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(base + byte_offset);
+#else
+    return byte_offset;
+#endif
+}
+__device__ inline uint2* late_arg_ptr(uint32_t byte_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) uint8_t* KernArg;
+    KernArg base = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    return *reinterpret_cast<uint2* const __attribute__((address_space(4)))*>(base + byte_offset);
+#else
+    return nullptr;
+#endif
+}
+
+// The shadow ray's direction record, read from the kernel-argument segment where it is first needed instead of at
+// the start of the kernel: fifteen scalar registers that would otherwise sit through the whole primary traversal,
+// and push the kernel over the 80 scalar registers that eight waves per SIMD leave each wave.
+__device__ inline RayDir late_shadow_dir() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) uint8_t* KernArg;
+    KernArg base = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));  // the loads below stay below
+    const __attribute__((address_space(4))) uint32_t* w = reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(
+        base + offsetof(PrimaryArgs, f) + offsetof(DevFrame, shadow));
+    RayDir r;
+    r.d = v3(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]));
+    r.inv = v3(__uint_as_float(w[3]), __uint_as_float(w[4]), __uint_as_float(w[5]));
+    r.t_delta = v3(__uint_as_float(w[6]), __uint_as_float(w[7]), __uint_as_float(w[8]));
+    r.sx = w[9], r.sy = w[10], r.sz = w[11];
+    r.dix = w[12], r.diy = w[13], r.diz = w[14];
+    return r;
+#else
+    return RayDir{};  // the host pass of the compiler only parses this
+#endif
+}
+static_assert(sizeof(RayDir) == 60 && offsetof(RayDir, sx) == 36 && offsetof(RayDir, dix) == 48, "late_shadow_dir reads RayDir word by word");
+
+// LATE: the kernel's arguments are exactly PrimaryArgs' members in that order, and what the epilogue needs of them is
+// read again there instead of being kept in scalar registers through both traversals.
+template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX, bool WIDE, bool LATE = false>
 __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* __restrict__ out_p,
                                            uint2* __restrict__ out_s, unsigned long long* stats) {
     const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
@@ -622,7 +678,8 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
                 HitRec oh;
                 n_rays++;
                 n_sr++;
-                if (trace_ray<WGSL, true, STATS, BOXES, TEX, WIDE>(s, so, f.shadow, oh, ctr)) {
+                const RayDir to_light = late_shadow_dir();
+                if (trace_ray<WGSL, true, STATS, BOXES, TEX, WIDE>(s, so, to_light, oh, ctr)) {
                     n_sh++;
                     sh = make_uint2(oh.id, __float_as_uint(oh.t));
                 }
@@ -630,9 +687,17 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
         }
     }
     if (in_tile) {
-        const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
-        out_p[oi] = ph;
-        if (SHADOW) out_s[oi] = sh;
+        if (LATE) {
+            const uint32_t tw = late_arg_u32(offsetof(PrimaryArgs, m) + offsetof(ShardMap, tile_w));
+            const uint32_t th = late_arg_u32(offsetof(PrimaryArgs, m) + offsetof(ShardMap, tile_h));
+            const size_t oi = (size_t)lt * tw * th + (size_t)ly * tw + lx;
+            late_arg_ptr(offsetof(PrimaryArgs, out_p))[oi] = ph;
+            if (SHADOW) late_arg_ptr(offsetof(PrimaryArgs, out_s))[oi] = sh;
+        } else {
+            const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
+            out_p[oi] = ph;
+            if (SHADOW) out_s[oi] = sh;
+        }
     }
     if (STATS) flush_stats(stats, n_rays, n_ph, n_sr, n_sh, ctr);
 }
@@ -641,6 +706,14 @@ template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX = false, bool 
 __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
                                                        uint2* __restrict__ out_s, unsigned long long* stats) {
     trace_primary_block<WGSL, SHADOW, STATS, BOXES, TEX, WIDE>(s, f, m, out_p, out_s, stats);
+}
+
+// k_trace_primary for triangle-only scenes without counters (the common case) inside 80 scalar registers: eight waves
+// per SIMD instead of seven.
+template <bool WGSL, bool SHADOW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_trace_primary_lean(
+    DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p, uint2* __restrict__ out_s) {
+    trace_primary_block<WGSL, SHADOW, 0, false, false, false, true>(s, f, m, out_p, out_s, nullptr);
 }
 
 // Pixel blocks that are expensive: a plan made by one launch for the next one of the same frame shape.
@@ -802,7 +875,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_tr
                 if (dot(n, d) > 0.0f) n = neg(n);
                 const V3 so = pos + n * f.shadow_offset;
                 HitRec oh;
-                if (trace_ray<WGSL, true, 0, false, false, false, TRACE_QUAD>(s, so, f.shadow, oh, ctr, qstep))
+                const RayDir to_light = late_shadow_dir();
+                if (trace_ray<WGSL, true, 0, false, false, false, TRACE_QUAD>(s, so, to_light, oh, ctr, qstep))
                     sh = make_uint2(oh.id, __float_as_uint(oh.t));
             }
         }

@@ -55,10 +55,10 @@ WORKLOAD = os.environ.get("RT_BENCH_WORKLOAD", "car1080")
 WIDTH, HEIGHT = (7680, 4320) if WORKLOAD == "massive8k" else (1920, 1080)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 TILE = 32
-# Measured on the headline frame: 2 in flight 73.9 us per frame, 3 in flight 71.9 (but a launch then spans three
-# overlapped launches, 226 us, and the per-launch roofline figure falls to 0.72 for the same kernel), 4 in flight 80.0.
-# RT_BENCH_IN_FLIGHT is a development switch; the default is what is reported.
-FRAMES_IN_FLIGHT = int(os.environ.get("RT_BENCH_IN_FLIGHT", "2"))
+# Measured on the headline frame (k_trace_primary_lean, eight waves per SIMD): 2 in flight 70.9 us per frame, 3 in
+# flight 68.8, 4 in flight 78.2 (a process has four hardware queues). RT_BENCH_IN_FLIGHT is a development switch; the
+# default is what is reported.
+FRAMES_IN_FLIGHT = int(os.environ.get("RT_BENCH_IN_FLIGHT", "3"))
 # At N > 1 a rank owns 1/N of the tiles but its slowest pixel block still is a ~100 us dependent chain, and every
 # frame also spends time on the links: more frames have to be in flight to keep the GPUs busy.
 # Frames per gather / assemble at N > 1 (rendered 16 to a launch). At N = 8 a rank's share of a frame is ~10 us of GPU

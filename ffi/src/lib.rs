@@ -52,6 +52,8 @@ extern "C" {
     pub fn rt_set_stream(ctx: *mut RtCtx, hip_stream: *mut c_void) -> c_int;
     pub fn rt_set_materials(ctx: *mut RtCtx, materials: *const c_void, n: u32) -> c_int;
     pub fn rt_get_trace_refs(ctx: *mut RtCtx, n_trace_refs: *mut u32) -> c_int;
+    /// What the last planned `rt_trace_primary` launch decided for the next one (params.heavy_block_threshold).
+    pub fn rt_get_heavy_blocks(ctx: *mut RtCtx, n_heavy: *mut u32, n_early: *mut u32, threshold_us: *mut u32) -> c_int;
     pub fn rt_set_textures(ctx: *mut RtCtx, textures: *const RtTexture, n: u32) -> c_int;
     pub fn rt_render_frames(ctx: *mut RtCtx, cameras: *const c_void, n_frames: u32, width: u32, height: u32,
                             shard: *const c_void, opts: *const c_void, out_rgba8: *mut u8) -> c_int;

@@ -318,7 +318,21 @@ def main():
         # device, straight into the scene buffers), grid binned locally on every GPU. The rehearsal on one GPU cannot
         # have an RCCL communicator (two ranks on one device are refused): torch.distributed over gloo stands in.
         if not rehearsal:
-            sharding.init_comm(core, rank, world)
+            # every rank must end up on the same route: if the library's communicator cannot be made on any of them
+            # (said loudly), all fall back to torch.distributed's RCCL process group for the broadcast and the gathers
+            try:
+                if os.environ.get("RT_BENCH_NO_NATIVE_COMM") == "1":  # development: exercise the fall-back
+                    raise RuntimeError("RT_BENCH_NO_NATIVE_COMM")
+                sharding.init_comm(core, rank, world)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                print(f"rank {rank}: rt_comm_init failed ({e}); torch.distributed collectives instead", file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and getattr(core, "comm_size", 0):
+                core.comm_destroy()
         sharding.replicate_scene(core, np.zeros(0, rt.BOX_DTYPE) if rank == 0 else None, tris)
     else:
         core.set_scene(None, tris)
@@ -469,7 +483,10 @@ def main():
         if multi and base_ms:
             out["speedup_vs_scaling_base"] = base_ms / ms_per_step
         out["timed_kernel"] = ("k_trace_primary_lean<shadow>: rt_hit records" if not multi else
-                               "k_render<single bounce, shadow term>: RGB8 picture, rt_gather_frames (RCCL), rt_assemble_frames")
+                               "k_render<single bounce, shadow term>: RGB8 picture, "
+                               + ("rt_gather_frames (RCCL through the C ABI)" if getattr(core, "comm_size", 0) else
+                                  "torch.distributed gather (the library's communicator could not be made)" if not rehearsal else
+                                  "host-staged gloo gather (one-GPU rehearsal)") + ", rt_assemble_frames")
         if not multi:
             abytes = algorithmic_bytes(stats)
             mbytes = moved_bytes(moved, WIDTH * HEIGHT)

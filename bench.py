@@ -312,7 +312,8 @@ def main():
                 "(models/no_animation, 3132 triangles, flattened to a fixture); no file or dataset is read in the timed region")
         workload = ("configs[1]: static model, 1920x1080 primary rays through the DDA uniform grid "
                     "+ one shadow ray per primary hit, SCENE=gltf start camera")
-    core = rt.TraceCore(local_rank)
+    # RT_BENCH_CULL=0 (development): every ray walks the grid, no mask of pixel blocks that cannot meet geometry
+    core = rt.TraceCore(local_rank, rt.default_params(cull_empty_blocks=int(os.environ.get("RT_BENCH_CULL", "1"))))
     if multi:
         # scene replicated by ONE RCCL broadcast through the C ABI (rt_comm_init + rt_broadcast_scene: device to
         # device, straight into the scene buffers), grid binned locally on every GPU. The rehearsal on one GPU cannot

@@ -13,7 +13,7 @@ pub const RT_MISS: u32 = 0xFFFF_FFFF;
 pub struct RtParams {
     pub finest_cell_size: f32, pub max_objects_per_cell: u32, pub max_dda_steps: u32, pub wgsl_compat: u32,
     pub lod_cull: u32, pub moving_box_count: u32, pub fov: f32, pub light_direction: [f32; 3],
-    pub shadow_offset: f32, pub collect_stats: u32, pub skip_duplicate_triangles: u32, pub heavy_block_threshold: u32,
+    pub shadow_offset: f32, pub collect_stats: u32, pub skip_duplicate_triangles: u32, pub heavy_block_threshold: u32, pub cull_empty_blocks: u32,
 }
 
 #[repr(C)]
@@ -54,6 +54,8 @@ extern "C" {
     pub fn rt_get_trace_refs(ctx: *mut RtCtx, n_trace_refs: *mut u32) -> c_int;
     /// What the last planned `rt_trace_primary` launch decided for the next one (params.heavy_block_threshold).
     pub fn rt_get_heavy_blocks(ctx: *mut RtCtx, n_heavy: *mut u32, n_early: *mut u32, threshold_us: *mut u32) -> c_int;
+    /// Frame blocks of the last `rt_trace_primary` launch and how many its block mask kept (params.cull_empty_blocks).
+    pub fn rt_get_cull_stats(ctx: *mut RtCtx, blocks_total: *mut u32, blocks_kept: *mut u32) -> c_int;
     pub fn rt_set_textures(ctx: *mut RtCtx, textures: *const RtTexture, n: u32) -> c_int;
     pub fn rt_render_frames(ctx: *mut RtCtx, cameras: *const c_void, n_frames: u32, width: u32, height: u32,
                             shard: *const c_void, opts: *const c_void, out_rgba8: *mut u8) -> c_int;

@@ -92,6 +92,15 @@ typedef struct rt_params {
                                          that wait for a few dense spots of the model (a frame of the animated phoenix:
                                          168 -> 77 us); a frame whose cost is spread evenly gains nothing and pays
                                          about 8 % for the bookkeeping. No reference counterpart */
+    uint32_t cull_empty_blocks;     /* 1 (default): before rt_trace_primary traces a frame of a triangle-only scene, a
+                                         small kernel projects the grid's occupied cells (each grown by a quarter of a
+                                         cell, far more than the float DDA of raytracer_unified.wgsl:492-588 can drift)
+                                         onto the frame and marks the 8x8 pixel blocks they can be seen through; a block
+                                         left unmarked has rays that meet no candidate list, so its 64 records are
+                                         written as misses without a traversal. The same answers bit for bit. Applies
+                                         when tiles are multiples of 8 pixels, the grid has at most 2^21 cells, no
+                                         counters are collected and no plan of expensive blocks is kept; otherwise, and
+                                         with 0, every ray walks the grid. No reference counterpart */
 } rt_params;
 
 /* Which pixels of a W x H frame one call traces. The frame is cut into
@@ -194,6 +203,11 @@ int rt_build_grid(rt_ctx* ctx, float cell_size, uint32_t max_per_cell, int mode)
  * last two may be NULL. Waits for that stream. Zeros (and the parameter) when no such launch has happened. No
  * reference counterpart. */
 int rt_get_heavy_blocks(rt_ctx* ctx, uint32_t* n_heavy, uint32_t* n_early, uint32_t* threshold_us);
+
+/* Of the 8x8 pixel blocks of the frame of the most recent rt_trace_primary launch on this context, how many its block
+ * mask (params.cull_empty_blocks) kept for tracing; zeros when that launch had no mask. Waits for that stream. No
+ * reference counterpart. */
+int rt_get_cull_stats(rt_ctx* ctx, uint32_t* blocks_total, uint32_t* blocks_kept);
 
 /* How the current grid was made: 0 = rt_build_grid's general path (sizes read back by the host between passes,
  * duplicate search, any scene), 1 = its rebuild path for scenes of up to 65 536 objects whose grid has been built

@@ -12,6 +12,7 @@
 
 #include "rt_trace_variants.hpp"
 #endif
+#include "rt_cull.hpp"
 #include "rt_render.hpp"
 
 using namespace rt;
@@ -497,12 +498,132 @@ BlockPlan make_block_plan(const rt_plan* p, uint32_t threshold_us) {
     return b;
 }
 
+constexpr size_t CULL_MAX_SLOTS = 8;         // streams with a block mask of their own, per context
+constexpr size_t CULL_MAX_WORDS = 16384;      // mask words a workgroup of k_block_mask can hold in LDS (an 8K frame: 16 200)
+constexpr uint32_t CULL_MAX_CELLS = 1u << 21;  // beyond this many grid cells a frame's mask costs more than it saves
+
+// Inverse of the 3x3 matrix with columns c0, c1, c2, as rows; false when it is singular (or not finite).
+static bool invert_columns(const double c0[3], const double c1[3], const double c2[3], double r0[3], double r1[3], double r2[3]) {
+    auto cross3 = [](const double a[3], const double b[3], double o[3]) {
+        o[0] = a[1] * b[2] - a[2] * b[1], o[1] = a[2] * b[0] - a[0] * b[2], o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    cross3(c1, c2, r0), cross3(c2, c0, r1), cross3(c0, c1, r2);
+    const double det = c0[0] * r0[0] + c0[1] * r0[1] + c0[2] * r0[2];
+    auto len = [](const double a[3]) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); };
+    const double scale = len(c0) * len(c1) * len(c2);
+    if (!(fabs(det) > 1e-9 * scale) || !(scale < 1e300)) return false;
+    for (int k = 0; k < 3; ++k) r0[k] /= det, r1[k] /= det, r2[k] /= det;
+    return true;
+}
+
+// The block mask for this frame (see rt_cull.hpp), queued on the context's stream ahead of the trace; *mask stays null
+// when the frame gets none: a parameter says so, the tiles do not line up with the frame's 8x8 blocks, the float DDA's
+// drift cannot be bounded tightly enough for this camera and grid, the camera basis is degenerate, the origin is one
+// that starts the traversal outside the grid, or the grid is so large that making the mask costs more than it saves.
+int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMap& m, const uint32_t** mask) {
+    *mask = nullptr;
+    if (!c->params.cull_empty_blocks || s.nb != 0) return RT_OK;
+    if ((m.tile_w & 7u) && !(m.tiles_x == 1)) return RT_OK;
+    if ((m.tile_h & 7u) && !(m.tiles_y == 1)) return RT_OK;
+    if (s.n_cells == 0 || s.n_cells > CULL_MAX_CELLS || !(s.cell_size > 0.0f)) return RT_OK;
+    const double cs = s.cell_size;
+    // the whole grid and the camera on a scale where float positions resolve far below a cell
+    double coord = 0.0, far2 = 0.0;
+    for (int corner = 0; corner < 8; ++corner) {
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double q = (corner >> k) & 1 ? s.bmax[k] : s.bmin[k];
+            coord = fmax(coord, fabs(q));
+            d2 += (q - f.cam_pos[k]) * (q - f.cam_pos[k]);
+        }
+        far2 = fmax(far2, d2);
+    }
+    for (int k = 0; k < 3; ++k) coord = fmax(coord, fabs((double)f.cam_pos[k]));
+    const double far = sqrt(far2) + 2.0 * cs;
+    const double steps = fmin((double)s.max_steps, (double)s.gx + s.gy + s.gz) + 8.0;
+    const double ulp = 1.0 / 16777216.0;
+    // drift of the DDA's boundary crossings, and of the positions they are computed from, in cells
+    if (!(steps * ulp * far / cs < 0.05) || !(16.0 * ulp * coord / cs < 0.01)) return RT_OK;
+    // an origin inside the bounds whose start cell is outside the grid takes the traversal's literal path (rt_trace.hpp)
+    bool inside = true;
+    for (int k = 0; k < 3; ++k) inside = inside && !(f.cam_pos[k] < s.bmin[k] || f.cam_pos[k] > s.bmax[k]);
+    if (inside) {
+        const uint32_t g[3] = {s.gx, s.gy, s.gz};
+        for (int k = 0; k < 3; ++k) {
+            const float rel = f.cam_pos[k] - s.bmin[k];
+            if (f2u_sat(fmaxf(0.0f, floorf(rel * s.inv_cell_size))) >= g[k]) return RT_OK;
+        }
+    }
+    CullFrame cf;
+    const double aspect = (double)((float)f.width / (float)f.height), fov = (double)f.fov_scale;
+    double c0[3], c1[3], c2[3];
+    for (int k = 0; k < 3; ++k) {
+        cf.o[k] = f.cam_pos[k];
+        c0[k] = f.fwd[k];
+        c1[k] = (double)f.right[k] * aspect * fov;
+        c2[k] = -(double)f.up[k] * fov;
+        if (!std::isfinite(cf.o[k]) || !std::isfinite(c0[k]) || !std::isfinite(c1[k]) || !std::isfinite(c2[k])) return RT_OK;
+    }
+    if (!invert_columns(c0, c1, c2, cf.r0, cf.r1, cf.r2)) return RT_OK;
+    double rn = 0.0;
+    for (int k = 0; k < 3; ++k) rn = fmax(rn, fmax(fabs(cf.r1[k]), fabs(cf.r2[k])));
+    cf.tol = 1e-9 * (far + coord) * 3.0 * rn;
+    cf.near_r = 1e-6 * cs;
+    cf.margin = 0.25 * cs + 0.002;
+    cf.width = f.width, cf.height = f.height;
+    cf.blocks_x = (f.width + 7u) >> 3, cf.blocks_y = (f.height + 7u) >> 3;
+    cf.words_per_row = (cf.blocks_x + 31u) >> 5;
+    const size_t words = (size_t)cf.blocks_y * cf.words_per_row;
+    if (words > CULL_MAX_WORDS) return RT_OK;
+
+    rt_cull* hit = nullptr;
+    for (rt_cull* k : c->culls)
+        if (k->stream == c->stream) hit = k;
+    if (!hit) {
+        if (c->culls.size() < CULL_MAX_SLOTS) {
+            hit = new rt_cull;
+            c->culls.push_back(hit);
+        } else {  // the slot used longest ago; nothing may still be reading it
+            for (rt_cull* k : c->culls)
+                if (!hit || k->last_use < hit->last_use) hit = k;
+            RT_HIP(c, hipDeviceSynchronize());
+        }
+        hit->stream = c->stream;
+    }
+    if (words * sizeof(uint32_t) > hit->buf[0].cap) {
+        // a larger frame on this stream: the old buffers may still be read by a launch queued before this one
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        for (int b = 0; b < 2; ++b) {
+            RT_HIP(c, hit->buf[b].reserve(words * sizeof(uint32_t)));
+            RT_HIP(c, hipMemsetAsync(hit->buf[b].p, 0, hit->buf[b].cap, c->stream));
+            hit->dirty[b] = 0;
+        }
+    }
+    const int fill = hit->cur ^ 1;
+    if (hit->dirty[fill]) {  // the trace launch that would have zeroed it did not happen (a frame without a mask in between)
+        RT_HIP(c, hipMemsetAsync(hit->buf[fill].p, 0, (size_t)hit->dirty[fill] * sizeof(uint32_t), c->stream));
+        hit->dirty[fill] = 0;
+    }
+    hit->last_use = ++c->plan_clock;
+    hit->words = (uint32_t)words;
+    hit->blocks = cf.blocks_x * cf.blocks_y;
+    hipLaunchKernelGGL(k_block_mask, dim3((s.n_cells + CULL_CELLS_PER_WAVE - 1u) / CULL_CELLS_PER_WAVE), dim3(64), words * sizeof(uint32_t), c->stream, s.cells, s.gx, s.gy, s.gz, s.px, s.pxy,
+                       s.bmin[0], s.bmin[1], s.bmin[2], s.cell_size, cf, hit->buf[fill].as<uint32_t>());
+    RT_HIP(c, hipGetLastError());
+    hit->dirty[fill] = (uint32_t)words;
+    hit->cur = fill;
+    c->last_cull = hit;
+    *mask = hit->buf[fill].as<uint32_t>();
+    return RT_OK;
+}
+
 // Kernel variants: WGSL (constant set), SHADOW / ANY, BOXES (scene has boxes), TEX (hits decided by a texture's
 // alpha). The counting build is the general one (with the box path); so is the build for grids of 4 GiB and more.
 template <bool WGSL, bool SHADOW>
 int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* op,
                    uint2* os, bool may_alloc) {
     unsigned long long* st = c->stats.as<unsigned long long>();
+    c->last_cull = nullptr;
 #ifdef RT_EXPERIMENTS
     if (const char* v = getenv("RT_VARIANT")) {
         if (!WGSL && SHADOW && !stats && s.nb == 0) {
@@ -526,7 +647,8 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
                 return RT_OK;
             }
             if (vn == 71) {  // the shipped kernel without a plan of expensive blocks
-                hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os);
+                const uint32_t* no_mask = nullptr;
+                hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os, no_mask, (uint32_t*)nullptr, 0u);
                 return RT_OK;
             }
             if (vn == 73) {  // the general kernel's instantiation for the same scenes: 86 scalar registers, seven waves per SIMD
@@ -570,7 +692,19 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
             hipLaunchKernelGGL((k_trace_primary_planned<WGSL, SHADOW>), dim3(grid.x + PLAN_LEAD_WGS), dim3(256), 0, c->stream, s, f, m, bp, op, os);
             plan->cur = (plan->cur + 1) % 3;
         } else {
-            hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os);
+            // the frame's mask of pixel blocks that can meet geometry, when one can be made (and may be allocated)
+            const uint32_t* mask = nullptr;
+            if (may_alloc)
+                if (int r = cull_mask_for(c, s, f, m, &mask)) return r;
+            uint32_t* zero = nullptr;  // the other buffer of the pair, for the next frame's mask: this launch zeroes it
+            uint32_t zero_words = 0;
+            if (mask) {
+                rt_cull* k = c->last_cull;
+                zero = k->buf[k->cur ^ 1].as<uint32_t>();
+                zero_words = k->dirty[k->cur ^ 1];
+                k->dirty[k->cur ^ 1] = 0;
+            }
+            hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os, mask, zero, zero_words);
         }
     }
     return RT_OK;
@@ -694,6 +828,7 @@ extern "C" void rt_default_params(rt_params* p) {
     p->collect_stats = 0;
     p->skip_duplicate_triangles = 1;
     p->heavy_block_threshold = 0;
+    p->cull_empty_blocks = 1;
 }
 
 extern "C" const char* rt_create_error(void) { return g_create_error.c_str(); }
@@ -772,6 +907,11 @@ extern "C" void rt_destroy(rt_ctx* c) {
     for (rt_plan* p : c->plans) {
         for (DevBuf& b : p->buf) b.release();
         delete p;
+    }
+    for (rt_cull* k : c->culls) {
+        k->buf[0].release();
+        k->buf[1].release();
+        delete k;
     }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -969,6 +1109,24 @@ extern "C" int rt_get_grid(rt_ctx* c, GridMetadata* meta, uint32_t* n_cells, uin
     if (meta) *meta = c->meta;
     if (n_cells) *n_cells = c->n_cells;
     if (n_refs) *n_refs = c->n_refs;
+    return RT_OK;
+}
+
+// Of the frame blocks (8x8 pixels) of the most recent rt_trace_primary launch on this context, how many its block mask
+// kept; both zero when that launch had no mask. Waits for the stream.
+extern "C" int rt_get_cull_stats(rt_ctx* c, uint32_t* blocks_total, uint32_t* blocks_kept) {
+    if (int r = use(c)) return r;
+    if (blocks_total) *blocks_total = 0;
+    if (blocks_kept) *blocks_kept = 0;
+    const rt_cull* k = c->last_cull;
+    if (!k) return RT_OK;
+    std::vector<uint32_t> host(k->words);
+    RT_HIP(c, hipMemcpyAsync(host.data(), k->buf[k->cur].p, (size_t)k->words * sizeof(uint32_t), hipMemcpyDeviceToHost, k->stream));
+    RT_HIP(c, hipStreamSynchronize(k->stream));
+    uint32_t kept = 0;
+    for (uint32_t w : host) kept += (uint32_t)__builtin_popcount(w);
+    if (blocks_total) *blocks_total = k->blocks;
+    if (blocks_kept) *blocks_kept = kept;
     return RT_OK;
 }
 

@@ -70,8 +70,23 @@ struct rt_plan {
     unsigned long long last_use = 0;
 };
 
+// Block mask of the frames traced on one stream (k_block_mask in rt_cull.hpp): the mask of a frame is made and read by
+// consecutive launches on that stream, so frames in flight on other streams need masks of their own.
+// Two buffers: a frame's mask kernel fills one (all zero when it starts), the trace kernel that follows reads it and
+// zeroes the other, which the next frame's mask kernel then fills - no launch of its own for the zeroing.
+struct rt_cull {
+    hipStream_t stream = nullptr;
+    rt::DevBuf buf[2];
+    uint32_t dirty[2] = {0, 0};      // leading words of each buffer that may be non-zero
+    int cur = 0;                     // the buffer of the most recent mask
+    uint32_t words = 0, blocks = 0;  // of the most recent mask made here
+    unsigned long long last_use = 0;
+};
+
 struct rt_ctx {
     int device = 0;
+    std::vector<rt_cull*> culls;
+    rt_cull* last_cull = nullptr;  // the mask of the most recent launch that had one (null: it had none)
     std::vector<rt_plan*> plans;
     unsigned long long plan_clock = 0;
     rt_plan* last_plan = nullptr;  // the plan of the most recent planned launch

@@ -594,6 +594,9 @@ struct PrimaryArgs {
     ShardMap m;
     uint2* out_p;
     uint2* out_s;
+    const uint32_t* cull_mask;  // k_trace_primary_lean only: one bit per 8x8 pixel block of the frame, or null
+    uint32_t* cull_zero;        // the mask buffer of the next frame on this stream: zeroed by this launch (or null)
+    uint32_t cull_zero_words;
 };
 
 // A word / a pointer of the kernel-argument segment, read where it is needed (see late_shadow_dir).
@@ -605,6 +608,15 @@ __device__ inline uint32_t late_arg_u32(uint32_t byte_offset) {
     return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(base + byte_offset);
 #else
     return byte_offset;
+#endif
+}
+__device__ inline const uint32_t* late_arg_cptr(uint32_t byte_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) uint8_t* KernArg;
+    KernArg base = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+    return *reinterpret_cast<const uint32_t* const __attribute__((address_space(4)))*>(base + byte_offset);
+#else
+    return nullptr;
 #endif
 }
 __device__ inline uint2* late_arg_ptr(uint32_t byte_offset) {
@@ -656,7 +668,22 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
     const uint32_t tile = shard_tile(m, lt);
     const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
     const bool in_tile = lx < m.tile_w && ly < m.tile_h;
-    const bool live = in_tile && px < f.width && py < f.height;
+    bool live = in_tile && px < f.width && py < f.height;
+    if (LATE) {
+        // A clear bit in the frame's block mask (k_block_mask in rt_cull.hpp): no primary ray of this wave's 8x8 pixel
+        // block meets an occupied cell, so all 64 records are misses. Tiles are whole multiples of 8 pixels when a mask
+        // is given, so the wave's block is one block of the frame's 8x8 raster; everything here is the same in every lane.
+        const uint32_t* mask = late_arg_cptr(offsetof(PrimaryArgs, cull_mask));
+        if (mask) {
+            const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile % m.tiles_x) * m.tile_w >> 3) + sub_x));
+            const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile / m.tiles_x) * m.tile_h >> 3) + sub_y));
+            const uint32_t blocks_x = (f.width + 7u) >> 3, blocks_y = (f.height + 7u) >> 3;
+            if (bx < blocks_x && by < blocks_y) {
+                const uint32_t word = mask[(size_t)by * ((blocks_x + 31u) >> 5) + (bx >> 5)];
+                if (((word >> (bx & 31u)) & 1u) == 0u) live = false;
+            }
+        }
+    }
 
     uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
     Counters ctr{};
@@ -712,7 +739,10 @@ __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, S
 // per SIMD instead of seven.
 template <bool WGSL, bool SHADOW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_trace_primary_lean(
-    DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p, uint2* __restrict__ out_s) {
+    DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p, uint2* __restrict__ out_s, const uint32_t* __restrict__ cull_mask,
+    uint32_t* __restrict__ cull_zero, uint32_t cull_zero_words) {
+    if (cull_zero)
+        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < cull_zero_words; k += gridDim.x * 256u) cull_zero[k] = 0u;
     trace_primary_block<WGSL, SHADOW, 0, false, false, false, true>(s, f, m, out_p, out_s, nullptr);
 }
 

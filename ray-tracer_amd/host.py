@@ -202,6 +202,13 @@ class TraceCore:
         self._ck(self._L.rt_get_heavy_blocks(self._h, C.byref(n), C.byref(e), C.byref(t)))
         return n.value, e.value, t.value
 
+    def cull_stats(self):
+        """(blocks, kept): 8x8 pixel blocks of the last trace_primary frame and how many its block mask kept for tracing
+        (rt_params.cull_empty_blocks); (0, 0) when that launch had no mask."""
+        n, k = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.rt_get_cull_stats(self._h, C.byref(n), C.byref(k)))
+        return n.value, k.value
+
     def build_path(self):
         """0: general build, 1: rebuild with every size kept on the device, -1: grid supplied by the caller."""
         v = C.c_int()

@@ -1,0 +1,153 @@
+"""The block mask (rt_params.cull_empty_blocks): 8x8 pixel blocks whose primary rays provably meet no occupied grid cell
+are written as misses without a traversal. The reference lets every ray walk the grid (raytracer_unified.wgsl:520-588)
+and knows no such mask, so the check is: with the mask and without it the records are the same bit for bit - and equal
+to the oracle's - for cameras outside, above, inside, on the bounds of and far away from the grid, for frame sizes that
+are no multiple of 8, for shards, for both constant sets, and for random poses; and the mask does cull where there is
+something to cull."""
+import math
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_hits_equal, ocam, oparams
+
+pytestmark = pytest.mark.gpu
+
+
+def both(rt, xyz9, **kw):
+    cores = []
+    for cull in (1, 0):
+        c = rt.TraceCore(0, rt.default_params(cull_empty_blocks=cull, **kw))
+        c.set_scene(None, rt.triangles_from_xyz9(xyz9))
+        c.build_grid()
+        cores.append(c)
+    return cores
+
+
+def same(on, off, cam, w, h, what, shard=None):
+    p1, s1 = on.trace_primary(cam, w, h, shard=shard)
+    stats = on.cull_stats()
+    p0, s0 = off.trace_primary(cam, w, h, shard=shard)
+    assert off.cull_stats() == (0, 0)
+    assert_hits_equal(p1, p0, f"{what}: primary, mask on against off")
+    assert_hits_equal(s1, s0, f"{what}: shadow, mask on against off")
+    return p1, s1, stats
+
+
+POSES = [
+    ("scene start camera", (200, 200, 300), 3.35, -0.28),
+    ("far outside, model small in the frame", (2500, 900, 2600), 3.9, -0.25),
+    ("outside, looking away", (900, 300, 900), 0.6, 0.1),
+    ("outside, looking straight down", (0, 900, 0), 0.0, -1.55),
+    ("inside the grid", (40, 60, -30), 1.0, -0.1),
+    ("inside, close above the floor", (-100, 3, 200), 2.2, 0.3),
+    ("grazing along the roof", (-700, 190, -900), 0.65, -0.02),
+    ("below the model looking up", (0, -400, 0), 0.3, 1.2),
+]
+
+
+@pytest.mark.parametrize("wgsl", [0, 1])
+def test_car_poses_mask_on_equals_off_and_oracle(rt, ob, car_xyz9, wgsl):
+    on, off = both(rt, car_xyz9, wgsl_compat=wgsl)
+    try:
+        scene = ob.Scene(None, ob.triangles_from_xyz9(car_xyz9))
+        culled_somewhere = 0
+        for k, (name, pos, yaw, pitch) in enumerate(POSES):
+            for (w, h) in ((480, 270), (333, 187)):
+                cam = rt.Camera(pos, yaw, pitch).to_uniform(0.0, float(h))
+                p, s, (blocks, kept) = same(on, off, cam, w, h, f"{name} {w}x{h}")
+                assert blocks == -(-w // 8) * -(-h // 8), (name, blocks)
+                ids = p["id"].reshape(h, w)
+                hit_blocks = sum(bool((ids[by:by + 8, bx:bx + 8] != rt.RT_MISS).any()) for by in range(0, h, 8) for bx in range(0, w, 8))
+                assert kept >= hit_blocks, (name, kept, hit_blocks)  # a block with a hit is never culled
+                culled_somewhere += blocks - kept
+                if k < 3 and (w, h) == (480, 270):  # against the oracle as well
+                    op, os_, _ = ob.trace_primary(scene, ocam(ob, cam), w, h, params=oparams(ob, on.params), n_threads=8)
+                    assert_hits_equal(p, op, f"{name}: primary against the oracle")
+                    assert_hits_equal(s, os_, f"{name}: shadow against the oracle")
+        assert culled_somewhere > 0
+    finally:
+        on.close(), off.close()
+
+
+def test_mask_culls_most_of_an_empty_sky_and_keeps_the_model(rt, car_xyz9):
+    on, off = both(rt, car_xyz9)
+    try:
+        w, h = 960, 540
+        cam = rt.Camera((2500, 900, 2600), 3.9, -0.25).to_uniform(0.0, float(h))
+        p, _, (blocks, kept) = same(on, off, cam, w, h, "far camera")
+        ids = p["id"].reshape(h, w)
+        hit_blocks = sum(bool((ids[by:by + 8, bx:bx + 8] != rt.RT_MISS).any()) for by in range(0, h, 8) for bx in range(0, w, 8))
+        assert hit_blocks > 0 and kept >= hit_blocks
+        # the grown cells' outline is a little larger than the model's: allow for it, but most of the frame must go
+        assert kept < 0.5 * blocks and kept < 4 * hit_blocks + 200, (blocks, kept, hit_blocks)
+    finally:
+        on.close(), off.close()
+
+
+def test_shards_and_tiles_that_do_not_line_up(rt, car_xyz9):
+    on, off = both(rt, car_xyz9)
+    try:
+        w, h = 500, 281
+        cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+        for (tw, th, first, stride) in ((32, 32, 0, 1), (64, 40, 1, 3), (32, 16, 2, 5), (8, 8, 0, 2)):
+            _, _, (blocks, kept) = same(on, off, cam, w, h, f"tiles {tw}x{th}", shard=rt.RtShard(tw, th, first, stride))
+            assert blocks > 0  # tiles of whole 8x8 blocks: a mask is made
+        for (tw, th) in ((30, 32), (32, 20), (17, 9)):  # no mask: a wave's block would straddle the frame's blocks
+            _, _, st = same(on, off, cam, w, h, f"tiles {tw}x{th}", shard=rt.RtShard(tw, th, 0, 2))
+            assert st == (0, 0)
+        # one tile = the whole frame, whatever its size
+        _, _, st = same(on, off, cam, w, h, "whole frame")
+        assert st[0] == -(-w // 8) * -(-h // 8)
+    finally:
+        on.close(), off.close()
+
+
+def test_random_poses_two_models_frames_in_flight(rt, ob, car_xyz9, phoenix_xyz9):
+    import torch
+    rng = np.random.default_rng(20261112)
+    for name, xyz9 in (("car", car_xyz9), ("phoenix", phoenix_xyz9)):
+        on, off = both(rt, xyz9)
+        try:
+            meta, _, _ = on.grid_info()
+            lo, hi = np.array(meta.bounds_min[:3]), np.array(meta.bounds_max[:3])
+            size = hi - lo
+            streams = [torch.cuda.Stream() for _ in range(3)]
+            for trial in range(40):
+                kind = trial % 4
+                if kind == 0:    # anywhere inside
+                    pos = lo + rng.uniform(0, 1, 3) * size
+                elif kind == 1:  # a shell around the grid
+                    pos = lo + rng.uniform(-0.6, 1.6, 3) * size
+                elif kind == 2:  # far away
+                    pos = (lo + hi) / 2 + rng.normal(0, 1, 3) * size.max() * 4
+                else:            # exactly on a face of the bounds, or within a hair of it
+                    pos = lo + rng.uniform(0, 1, 3) * size
+                    ax = int(rng.integers(3))
+                    pos[ax] = (lo, hi)[int(rng.integers(2))][ax] + (0.0, 1e-4, -1e-4)[int(rng.integers(3))]
+                yaw, pitch = rng.uniform(0, 2 * math.pi), rng.uniform(-1.5, 1.5)
+                w, h = int(rng.integers(40, 400)), int(rng.integers(30, 260))
+                cam = rt.Camera(tuple(float(v) for v in pos), yaw, pitch).to_uniform(float(rng.uniform(0, 3)), float(h))
+                on.set_stream(streams[trial % 3].cuda_stream)  # masks are per stream
+                same(on, off, cam, w, h, f"{name} trial {trial} kind {kind} pos {pos} yaw {yaw:.3f} pitch {pitch:.3f} {w}x{h}")
+        finally:
+            on.close(), off.close()
+
+
+def test_degenerate_camera_basis_gets_no_mask(rt, car_xyz9):
+    on, off = both(rt, car_xyz9)
+    try:
+        w, h = 160, 90
+        cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+        cam.right[0], cam.right[1], cam.right[2] = cam.forward[0], cam.forward[1], cam.forward[2]  # not a basis
+        _, _, st = same(on, off, cam, w, h, "right = forward")
+        assert st == (0, 0)
+        # a basis that is skewed and scaled is still a basis: the mask follows the pixel directions the kernel makes
+        cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(h))
+        cam.right[0] *= 1.7
+        cam.up[1] *= 0.6
+        cam.up[0] += 0.2
+        _, _, st = same(on, off, cam, w, h, "skewed basis")
+        assert st[0] > 0
+    finally:
+        on.close(), off.close()

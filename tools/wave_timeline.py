@@ -31,7 +31,7 @@ p = torch.empty((W * H, 2), dtype=torch.int32, device="cuda")
 s = torch.empty_like(p)
 nw = ((W + 15) // 16) * ((H + 15) // 16) * 4
 os.environ["RT_VARIANT"] = VARIANT
-for _ in range(5):
+for _ in range(int(os.environ.get("RT_FRAMES", "5"))):
     core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
 core.sync()
 buf = np.zeros(2 * nw, np.uint64)
@@ -55,6 +55,16 @@ for e in edges:
     print(f"  t={e:6.1f} us  resident waves {n:6d}")
 hits = p.cpu().numpy().view(rt.HIT_DTYPE).reshape(H, W)
 bx = (W + 15) // 16
+if W % 16 == 0 and H % 8 == 0:
+    # run time of the waves whose 8x8 block holds no primary hit at all
+    any_hit = (hits["id"] != rt.RT_MISS).reshape(H // 8, 8, W // 8, 8).any(axis=(1, 3))
+    gws = np.arange(nw)
+    b16s, g4s = gws >> 2, gws & 3
+    x8s, y8s = (b16s % bx) * 2 + (g4s & 1), (b16s // bx) * 2 + (g4s >> 1)
+    ok = live & (y8s < H // 8)
+    miss_block = ok & ~any_hit[np.minimum(y8s, H // 8 - 1), x8s]
+    print(f"blocks without a primary hit: {miss_block.sum()} of {ok.sum()}, their run times sum to {dur[miss_block].sum() / 1e3:.2f} "
+          f"of {dur[ok].sum() / 1e3:.2f} wave-ms (mean {dur[miss_block].mean():.2f} us against {dur[ok & ~miss_block].mean():.2f} us)")
 print("waves that ended last: (block x, y of 8x8), start, run time")
 for gw in np.argsort(-np.where(live, t1, 0))[:24]:
     b16, g4 = gw >> 2, gw & 3

@@ -98,6 +98,9 @@ def count_frame(core, cam, width, height, outs):
     core.set_collect_stats(2)
     core.trace_primary(cam, width, height, shadow=True, out_primary=outs[0], out_shadow=outs[1])
     mov = core.stats()
+    # the count above follows the frame's mask of pixel blocks that can meet geometry, as launches with frames in
+    # flight do: (blocks of the frame, blocks traced); zeros when this frame gets no mask
+    mov["pixel_blocks"], mov["pixel_blocks_traced"] = core.cull_stats()
     core.set_collect_stats(0)
     return ref, mov
 
@@ -345,6 +348,7 @@ def main():
     stats, moved = count_frame(core, cam, WIDTH, HEIGHT, cnt)
     del cnt
     rays_per_frame = stats["rays"]
+    cull_blocks, cull_kept = moved["pixel_blocks"], moved["pixel_blocks_traced"]
 
     if not multi:
         streams = [torch.cuda.Stream(device=dev) for _ in range(FRAMES_IN_FLIGHT)]
@@ -470,6 +474,7 @@ def main():
                        "width": WIDTH, "height": HEIGHT, "rays_per_frame": rays_per_frame,
                        "primary_hits": stats["primary_hits"], "grid": list(meta.fine_dims), "cell_size": 16.0,
                        "cells": n_cells, "cell_refs": n_refs, "trace_refs": core.trace_refs(),
+                       "pixel_blocks": cull_blocks, "pixel_blocks_traced": cull_kept,
                        "frames_in_flight": FRAMES_IN_FLIGHT if not multi else GROUP * GROUPS_IN_FLIGHT,
                        "frames_per_gather": 1 if not multi else GROUP, "frames_per_launch": 1 if not multi else min(GROUP, 16),
                        "output": "rt_hit records, 16 B per pixel, resident in HBM" if not multi else
@@ -499,6 +504,8 @@ def main():
                     "fetched_bytes_per_launch": mbytes, "fetched_GBps": mbytes / frame_s / 1e9,
                     "cell_records_fetched": moved["cell_records_fetched"], "ref_records_fetched": moved["ref_records_fetched"],
                     "ref_records_staged": moved["ref_records_staged"], "measured_copy_GBps": hbm_copy,
+                    "mask_kernel": ("k_block_mask (the frame's mask of 8x8 pixel blocks that can meet geometry, rt_params.cull_empty_blocks) "
+                                    "runs ahead of every launch on the same stream; kernel_ms and single_frame_us cover both"),
                     "note": ("algorithmic bytes are the reference algorithm's (every list entry of every visited cell, 8 B per cell, "
                              "40 B per candidate, 8 B per ray); fetched bytes are what the timed kernel requests from the memory "
                              "system; traffic is what reached HBM (hardware counters). Rates are per frame of the timed region "

@@ -92,15 +92,19 @@ typedef struct rt_params {
                                          that wait for a few dense spots of the model (a frame of the animated phoenix:
                                          168 -> 77 us); a frame whose cost is spread evenly gains nothing and pays
                                          about 8 % for the bookkeeping. No reference counterpart */
-    uint32_t cull_empty_blocks;     /* 1 (default): before rt_trace_primary traces a frame of a triangle-only scene, a
-                                         small kernel projects the grid's occupied cells (each grown by a quarter of a
-                                         cell, far more than the float DDA of raytracer_unified.wgsl:492-588 can drift)
-                                         onto the frame and marks the 8x8 pixel blocks they can be seen through; a block
-                                         left unmarked has rays that meet no candidate list, so its 64 records are
-                                         written as misses without a traversal. The same answers bit for bit. Applies
-                                         when tiles are multiples of 8 pixels, the grid has at most 2^21 cells, no
-                                         counters are collected and no plan of expensive blocks is kept; otherwise, and
-                                         with 0, every ray walks the grid. No reference counterpart */
+    uint32_t cull_empty_blocks;     /* Before rt_trace_primary traces a frame of a triangle-only scene, a small kernel can
+                                         project the grid's occupied cells (each grown by a quarter of a cell, far more
+                                         than the float DDA of raytracer_unified.wgsl:492-588 can drift) onto the frame
+                                         and mark the 8x8 pixel blocks they can be seen through; a block left unmarked
+                                         has rays that meet no candidate list, so its 64 records are written as misses
+                                         without a traversal. The same answers bit for bit.
+                                         0: never. 1 (default): while earlier frames of this context are still running on
+                                         the GPU (frames in flight: the extra launch is hidden and the saved traversals
+                                         are time gained; a lone frame on an idle GPU waits for its longest waves either
+                                         way and would only start later). 2: always.
+                                         Applies when tiles are multiples of 8 pixels, the grid has at most 2^21 cells, the
+                                         frame at most 2^19 blocks, and no plan of expensive blocks is kept; otherwise
+                                         every ray walks the grid. No reference counterpart */
 } rt_params;
 
 /* Which pixels of a W x H frame one call traces. The frame is cut into

@@ -450,6 +450,7 @@ constexpr uint32_t PLAN_CAP_HEAVY = 1024;  // most 8x8 blocks a plan traces four
 constexpr uint32_t PLAN_CAP_EARLY = 4096;  // most it moves to the front as they are: a quarter as many workgroups
 constexpr uint32_t PLAN_LEAD_WGS = PLAN_CAP_HEAVY + PLAN_CAP_EARLY / 4;  // lead every planned launch
 constexpr size_t PLAN_MAX_SLOTS = 8;       // (stream, frame shape) pairs remembered per context
+constexpr size_t CULL_MAX_SLOTS = 8;       // streams with a block mask of their own, per context
 
 // The plan for this stream and frame shape, made on first use (which allocates: the entry point that must not allocate
 // never comes here). *plan stays null when there is none to be had; the caller then launches the plain kernel.
@@ -498,7 +499,6 @@ BlockPlan make_block_plan(const rt_plan* p, uint32_t threshold_us) {
     return b;
 }
 
-constexpr size_t CULL_MAX_SLOTS = 8;         // streams with a block mask of their own, per context
 constexpr size_t CULL_MAX_WORDS = 16384;      // mask words a workgroup of k_block_mask can hold in LDS (an 8K frame: 16 200)
 constexpr uint32_t CULL_MAX_CELLS = 1u << 21;  // beyond this many grid cells a frame's mask costs more than it saves
 
@@ -520,9 +520,43 @@ static bool invert_columns(const double c0[3], const double c1[3], const double 
 // when the frame gets none: a parameter says so, the tiles do not line up with the frame's 8x8 blocks, the float DDA's
 // drift cannot be bounded tightly enough for this camera and grid, the camera basis is degenerate, the origin is one
 // that starts the traversal outside the grid, or the grid is so large that making the mask costs more than it saves.
-int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMap& m, const uint32_t** mask) {
+// True while a frame traced through this context may still be running on any of its streams.
+static bool frames_in_flight(rt_ctx* c) {
+    for (const rt_inflight& e : c->inflight)
+        if (hipEventQuery(e.done) == hipErrorNotReady) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+// After a trace launch on the context's stream: the event that frames_in_flight() asks.
+static int mark_in_flight(rt_ctx* c) {
+    rt_inflight* hit = nullptr;
+    for (rt_inflight& e : c->inflight)
+        if (e.stream == c->stream) hit = &e;
+    if (!hit) {
+        if (c->inflight.size() < CULL_MAX_SLOTS) {
+            rt_inflight fresh;
+            RT_HIP(c, hipEventCreateWithFlags(&fresh.done, hipEventDisableTiming));
+            c->inflight.push_back(fresh);
+            hit = &c->inflight.back();
+        } else {
+            for (rt_inflight& e : c->inflight)
+                if (!hit || e.last_use < hit->last_use) hit = &e;
+        }
+        hit->stream = c->stream;
+    }
+    hit->last_use = ++c->plan_clock;
+    RT_HIP(c, hipEventRecord(hit->done, c->stream));
+    return RT_OK;
+}
+
+int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMap& m, const uint32_t** mask, bool always) {
     *mask = nullptr;
     if (!c->params.cull_empty_blocks || s.nb != 0) return RT_OK;
+    // 1: only while earlier frames are still running. The mask is one more launch the trace has to wait for: with
+    // frames in flight that wait is hidden and the traversals it saves are time gained; a frame traced on an idle GPU
+    // waits for its few longest waves whatever the others do, and would only start later.
+    if (c->params.cull_empty_blocks == 1 && !always && !frames_in_flight(c)) return RT_OK;
     if ((m.tile_w & 7u) && !(m.tiles_x == 1)) return RT_OK;
     if ((m.tile_h & 7u) && !(m.tiles_y == 1)) return RT_OK;
     if (s.n_cells == 0 || s.n_cells > CULL_MAX_CELLS || !(s.cell_size > 0.0f)) return RT_OK;
@@ -544,7 +578,18 @@ int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMa
     const double ulp = 1.0 / 16777216.0;
     // drift of the DDA's boundary crossings, and of the positions they are computed from, in cells
     if (!(steps * ulp * far / cs < 0.05) || !(16.0 * ulp * coord / cs < 0.01)) return RT_OK;
-    // an origin inside the bounds whose start cell is outside the grid takes the traversal's literal path (rt_trace.hpp)
+    // A start cell outside the grid sends the traversal down its literal path, whose wrapped cell index follows no ray
+    // (rt_trace.hpp). An entering ray starts at most at fl(bmax - 1e-4) (raytracer_unified.wgsl:483-488), and the start
+    // coordinate is monotonic in the position: if even that one is inside the grid, every entering ray's is.
+    {
+        const uint32_t g[3] = {s.gx, s.gy, s.gz};
+        for (int k = 0; k < 3; ++k) {
+            const float top = s.bmax[k] - 0.0001f;
+            const float rel = top - s.bmin[k];
+            if (f2u_sat(fmaxf(0.0f, floorf(rel * s.inv_cell_size))) >= g[k]) return RT_OK;
+        }
+    }
+    // ... and so does an origin inside the bounds whose own start cell is outside the grid
     bool inside = true;
     for (int k = 0; k < 3; ++k) inside = inside && !(f.cam_pos[k] < s.bmin[k] || f.cam_pos[k] > s.bmax[k]);
     if (inside) {
@@ -652,7 +697,7 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
                 return RT_OK;
             }
             if (vn == 73) {  // the general kernel's instantiation for the same scenes: 86 scalar registers, seven waves per SIMD
-                hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+                hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, (const uint32_t*)nullptr);
                 return RT_OK;
             }
             switch (vn) {
@@ -663,25 +708,29 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
         }
     }
 #endif
-    // the two counting builds (1: the reference's work, 2: this library's fetches) are the general kernels
+    // the two counting builds (1: the reference's work, 2: this library's fetches) are the general kernels; the second
+    // follows the frame's block mask as the timed kernel does (a block that is not traced fetches nothing)
+    const uint32_t* nm = nullptr;
+    if (stats == 2 && may_alloc && c->tex_mode != 2 && !wide_grid(s))
+        if (int r = cull_mask_for(c, s, f, m, &nm, true)) return r;
     if (wide_grid(s)) {
         if (stats == 2)
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 2, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 2, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
         else if (stats)
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 1, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 1, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
         else
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
     } else if (stats == 2) {
-        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 2, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 2, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
     } else if (stats) {
-        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 1, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 1, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
     } else if (c->tex_mode == 2) {  // hits decided by a texture's alpha: the general kernel with the material path
         if (s.nb != 0)
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
         else
-            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+            hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, false, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
     } else if (s.nb != 0)
-        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
+        hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
     else {
         // triangles only, no counters: the kernel that keeps a plan of expensive pixel blocks, when it may
         rt_plan* plan = nullptr;
@@ -695,7 +744,7 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
             // the frame's mask of pixel blocks that can meet geometry, when one can be made (and may be allocated)
             const uint32_t* mask = nullptr;
             if (may_alloc)
-                if (int r = cull_mask_for(c, s, f, m, &mask)) return r;
+                if (int r = cull_mask_for(c, s, f, m, &mask, false)) return r;
             uint32_t* zero = nullptr;  // the other buffer of the pair, for the next frame's mask: this launch zeroes it
             uint32_t zero_words = 0;
             if (mask) {
@@ -705,6 +754,8 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
                 k->dirty[k->cur ^ 1] = 0;
             }
             hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os, mask, zero, zero_words);
+            if (may_alloc && c->params.cull_empty_blocks == 1)
+                if (int r = mark_in_flight(c)) return r;
         }
     }
     return RT_OK;
@@ -908,6 +959,8 @@ extern "C" void rt_destroy(rt_ctx* c) {
         for (DevBuf& b : p->buf) b.release();
         delete p;
     }
+    for (rt_inflight& e : c->inflight)
+        if (e.done) (void)hipEventDestroy(e.done);
     for (rt_cull* k : c->culls) {
         k->buf[0].release();
         k->buf[1].release();

@@ -83,8 +83,16 @@ struct rt_cull {
     unsigned long long last_use = 0;
 };
 
+// "Is a frame of this context still running?": one event per stream that has traced (recorded after the launch).
+struct rt_inflight {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    unsigned long long last_use = 0;
+};
+
 struct rt_ctx {
     int device = 0;
+    std::vector<rt_inflight> inflight;
     std::vector<rt_cull*> culls;
     rt_cull* last_cull = nullptr;  // the mask of the most recent launch that had one (null: it had none)
     std::vector<rt_plan*> plans;

@@ -657,7 +657,7 @@ static_assert(sizeof(RayDir) == 60 && offsetof(RayDir, sx) == 36 && offsetof(Ray
 // read again there instead of being kept in scalar registers through both traversals.
 template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX, bool WIDE, bool LATE = false>
 __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* __restrict__ out_p,
-                                           uint2* __restrict__ out_s, unsigned long long* stats) {
+                                           uint2* __restrict__ out_s, unsigned long long* stats, const uint32_t* cull_mask = nullptr) {
     const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
     const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;  // 16x16 blocks per tile
     const uint32_t blk_per_tile = blk_x * blk_y;
@@ -668,12 +668,13 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
     const uint32_t tile = shard_tile(m, lt);
     const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
     const bool in_tile = lx < m.tile_w && ly < m.tile_h;
-    bool live = in_tile && px < f.width && py < f.height;
-    if (LATE) {
+    const bool in_frame = in_tile && px < f.width && py < f.height;
+    bool live = in_frame;
+    {
         // A clear bit in the frame's block mask (k_block_mask in rt_cull.hpp): no primary ray of this wave's 8x8 pixel
         // block meets an occupied cell, so all 64 records are misses. Tiles are whole multiples of 8 pixels when a mask
         // is given, so the wave's block is one block of the frame's 8x8 raster; everything here is the same in every lane.
-        const uint32_t* mask = late_arg_cptr(offsetof(PrimaryArgs, cull_mask));
+        const uint32_t* mask = LATE ? late_arg_cptr(offsetof(PrimaryArgs, cull_mask)) : cull_mask;
         if (mask) {
             const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile % m.tiles_x) * m.tile_w >> 3) + sub_x));
             const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile / m.tiles_x) * m.tile_h >> 3) + sub_y));
@@ -688,6 +689,7 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
     uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
     Counters ctr{};
     unsigned long long n_rays = 0, n_ph = 0, n_sr = 0, n_sh = 0;
+    if (STATS && in_frame && !live) n_rays++;  // a ray answered by the block mask is still a ray of the frame
     if (live) {
         const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         const V3 d = primary_dir(f, px, py);
@@ -731,8 +733,9 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
 
 template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX = false, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_trace_primary(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
-                                                       uint2* __restrict__ out_s, unsigned long long* stats) {
-    trace_primary_block<WGSL, SHADOW, STATS, BOXES, TEX, WIDE>(s, f, m, out_p, out_s, stats);
+                                                       uint2* __restrict__ out_s, unsigned long long* stats,
+                                                       const uint32_t* __restrict__ cull_mask) {
+    trace_primary_block<WGSL, SHADOW, STATS, BOXES, TEX, WIDE>(s, f, m, out_p, out_s, stats, cull_mask);
 }
 
 // k_trace_primary for triangle-only scenes without counters (the common case) inside 80 scalar registers: eight waves

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def both(rt, xyz9, **kw):
     cores = []
-    for cull in (1, 0):
+    for cull in (2, 0):  # 2: a mask for every frame (1, the default, only while earlier frames are still running)
         c = rt.TraceCore(0, rt.default_params(cull_empty_blocks=cull, **kw))
         c.set_scene(None, rt.triangles_from_xyz9(xyz9))
         c.build_grid()
@@ -151,3 +151,38 @@ def test_degenerate_camera_basis_gets_no_mask(rt, car_xyz9):
         assert st[0] > 0
     finally:
         on.close(), off.close()
+
+
+def test_default_mode_masks_only_while_frames_are_in_flight(rt, car_xyz9):
+    import torch
+    core = rt.TraceCore(0, rt.default_params())  # cull_empty_blocks = 1
+    off = rt.TraceCore(0, rt.default_params(cull_empty_blocks=0))
+    try:
+        for c in (core, off):
+            c.set_scene(None, rt.triangles_from_xyz9(car_xyz9))
+            c.build_grid()
+        w, h = 960, 540
+        cam = rt.Camera((2500, 900, 2600), 3.9, -0.25).to_uniform(0.0, float(h))
+        want_p, want_s = off.trace_primary(cam, w, h)
+        # one frame at a time (the call returns host arrays, so the GPU is idle when the next one starts): no mask
+        for _ in range(3):
+            p, s = core.trace_primary(cam, w, h)
+            assert core.cull_stats() == (0, 0)
+            assert_hits_equal(p, want_p, "lone frame: primary")
+            assert_hits_equal(s, want_s, "lone frame: shadow")
+        # frames queued behind each other on two streams: those that find an earlier one still running get a mask
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        outs = [(torch.empty((w * h, 2), dtype=torch.int32, device="cuda"), torch.empty((w * h, 2), dtype=torch.int32, device="cuda"))
+                for _ in range(2)]
+        masked = 0
+        for k in range(24):
+            core.set_stream(streams[k % 2].cuda_stream)
+            core.trace_primary(cam, w, h, out_primary=outs[k % 2][0], out_shadow=outs[k % 2][1])
+        masked = core.cull_stats()  # of the last launch; waits for its stream
+        torch.cuda.synchronize()
+        assert masked[0] == -(-w // 8) * -(-h // 8) and 0 < masked[1] < masked[0], masked
+        for op, os_ in outs:
+            assert_hits_equal(op.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want_p, "frames in flight: primary")
+            assert_hits_equal(os_.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want_s, "frames in flight: shadow")
+    finally:
+        core.close(), off.close()

@@ -462,10 +462,23 @@ def test_stats_equal_oracle_counts(core, ob, rt, car_xyz9):
     mov = core.stats()
     assert all(mov[k] == st[k] for k in ("rays", "primary_hits", "shadow_rays", "shadow_hits"))
     assert mov["cells_visited"] == mov["tri_tests"] == mov["box_tests"] == 0
-    assert st["cells_visited"] <= mov["cell_records_fetched"] <= st["cells_visited"] + st["rays"]
+    # the frame's block mask (rt_params.cull_empty_blocks) is followed by this count as by the timed kernels: pixel blocks
+    # that cannot meet geometry fetch nothing
+    assert 0 < mov["cell_records_fetched"] <= st["cells_visited"] + st["rays"]
     assert 0 < mov["cell_records_uniform"] <= mov["cell_records_fetched"]
     assert 0 < mov["ref_records_fetched"] + mov["ref_records_staged"] <= 2 * st["tri_tests"] + st["cells_visited"]
     core.set_collect_stats(False)
+    plain = rt.TraceCore(0, rt.default_params(cull_empty_blocks=0, collect_stats=2))
+    try:
+        setup_scene(plain, ob, None, ob.triangles_from_xyz9(car_xyz9))
+        check_frame(plain, ob, scene, cam, 240, 135, what="stats, fetch counting, no block mask")
+        every = plain.stats()
+        assert all(every[k] == st[k] for k in ("rays", "primary_hits", "shadow_rays", "shadow_hits"))
+        assert st["cells_visited"] <= every["cell_records_fetched"] <= st["cells_visited"] + st["rays"]
+        assert mov["cell_records_fetched"] < every["cell_records_fetched"]
+        assert mov["ref_records_fetched"] + mov["ref_records_staged"] <= every["ref_records_fetched"] + every["ref_records_staged"]
+    finally:
+        plain.close()
 
 
 def test_debug_pixel(core, ob, rt, car_xyz9):

@@ -516,10 +516,6 @@ static bool invert_columns(const double c0[3], const double c1[3], const double 
     return true;
 }
 
-// The block mask for this frame (see rt_cull.hpp), queued on the context's stream ahead of the trace; *mask stays null
-// when the frame gets none: a parameter says so, the tiles do not line up with the frame's 8x8 blocks, the float DDA's
-// drift cannot be bounded tightly enough for this camera and grid, the camera basis is degenerate, the origin is one
-// that starts the traversal outside the grid, or the grid is so large that making the mask costs more than it saves.
 // True while a frame traced through this context may still be running on any of its streams.
 static bool frames_in_flight(rt_ctx* c) {
     for (const rt_inflight& e : c->inflight)
@@ -550,16 +546,11 @@ static int mark_in_flight(rt_ctx* c) {
     return RT_OK;
 }
 
-int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMap& m, const uint32_t** mask, bool always) {
-    *mask = nullptr;
-    if (!c->params.cull_empty_blocks || s.nb != 0) return RT_OK;
-    // 1: only while earlier frames are still running. The mask is one more launch the trace has to wait for: with
-    // frames in flight that wait is hidden and the traversals it saves are time gained; a frame traced on an idle GPU
-    // waits for its few longest waves whatever the others do, and would only start later.
-    if (c->params.cull_empty_blocks == 1 && !always && !frames_in_flight(c)) return RT_OK;
-    if ((m.tile_w & 7u) && !(m.tiles_x == 1)) return RT_OK;
-    if ((m.tile_h & 7u) && !(m.tiles_y == 1)) return RT_OK;
-    if (s.n_cells == 0 || s.n_cells > CULL_MAX_CELLS || !(s.cell_size > 0.0f)) return RT_OK;
+// Whether this frame can have a block mask (see cull_masks_for), and what k_block_mask needs for it.
+static bool cull_frame(const DevScene& s, const DevFrame& f, const ShardMap& m, CullFrame* cf) {
+    if ((m.tile_w & 7u) && !(m.tiles_x == 1)) return false;
+    if ((m.tile_h & 7u) && !(m.tiles_y == 1)) return false;
+    if (s.n_cells == 0 || s.n_cells > CULL_MAX_CELLS || !(s.cell_size > 0.0f)) return false;
     const double cs = s.cell_size;
     // the whole grid and the camera on a scale where float positions resolve far below a cell
     double coord = 0.0, far2 = 0.0;
@@ -577,7 +568,7 @@ int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMa
     const double steps = fmin((double)s.max_steps, (double)s.gx + s.gy + s.gz) + 8.0;
     const double ulp = 1.0 / 16777216.0;
     // drift of the DDA's boundary crossings, and of the positions they are computed from, in cells
-    if (!(steps * ulp * far / cs < 0.05) || !(16.0 * ulp * coord / cs < 0.01)) return RT_OK;
+    if (!(steps * ulp * far / cs < 0.05) || !(16.0 * ulp * coord / cs < 0.01)) return false;
     // A start cell outside the grid sends the traversal down its literal path, whose wrapped cell index follows no ray
     // (rt_trace.hpp). An entering ray starts at most at fl(bmax - 1e-4) (raytracer_unified.wgsl:483-488), and the start
     // coordinate is monotonic in the position: if even that one is inside the grid, every entering ray's is.
@@ -586,7 +577,7 @@ int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMa
         for (int k = 0; k < 3; ++k) {
             const float top = s.bmax[k] - 0.0001f;
             const float rel = top - s.bmin[k];
-            if (f2u_sat(fmaxf(0.0f, floorf(rel * s.inv_cell_size))) >= g[k]) return RT_OK;
+            if (f2u_sat(fmaxf(0.0f, floorf(rel * s.inv_cell_size))) >= g[k]) return false;
         }
     }
     // ... and so does an origin inside the bounds whose own start cell is outside the grid
@@ -596,30 +587,49 @@ int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMa
         const uint32_t g[3] = {s.gx, s.gy, s.gz};
         for (int k = 0; k < 3; ++k) {
             const float rel = f.cam_pos[k] - s.bmin[k];
-            if (f2u_sat(fmaxf(0.0f, floorf(rel * s.inv_cell_size))) >= g[k]) return RT_OK;
+            if (f2u_sat(fmaxf(0.0f, floorf(rel * s.inv_cell_size))) >= g[k]) return false;
         }
     }
-    CullFrame cf;
     const double aspect = (double)((float)f.width / (float)f.height), fov = (double)f.fov_scale;
     double c0[3], c1[3], c2[3];
     for (int k = 0; k < 3; ++k) {
-        cf.o[k] = f.cam_pos[k];
+        cf->o[k] = f.cam_pos[k];
         c0[k] = f.fwd[k];
         c1[k] = (double)f.right[k] * aspect * fov;
         c2[k] = -(double)f.up[k] * fov;
-        if (!std::isfinite(cf.o[k]) || !std::isfinite(c0[k]) || !std::isfinite(c1[k]) || !std::isfinite(c2[k])) return RT_OK;
+        if (!std::isfinite(cf->o[k]) || !std::isfinite(c0[k]) || !std::isfinite(c1[k]) || !std::isfinite(c2[k])) return false;
     }
-    if (!invert_columns(c0, c1, c2, cf.r0, cf.r1, cf.r2)) return RT_OK;
+    if (!invert_columns(c0, c1, c2, cf->r0, cf->r1, cf->r2)) return false;
     double rn = 0.0;
-    for (int k = 0; k < 3; ++k) rn = fmax(rn, fmax(fabs(cf.r1[k]), fabs(cf.r2[k])));
-    cf.tol = 1e-9 * (far + coord) * 3.0 * rn;
-    cf.near_r = 1e-6 * cs;
-    cf.margin = 0.25 * cs + 0.002;
-    cf.width = f.width, cf.height = f.height;
-    cf.blocks_x = (f.width + 7u) >> 3, cf.blocks_y = (f.height + 7u) >> 3;
-    cf.words_per_row = (cf.blocks_x + 31u) >> 5;
-    const size_t words = (size_t)cf.blocks_y * cf.words_per_row;
-    if (words > CULL_MAX_WORDS) return RT_OK;
+    for (int k = 0; k < 3; ++k) rn = fmax(rn, fmax(fabs(cf->r1[k]), fabs(cf->r2[k])));
+    cf->tol = 1e-9 * (far + coord) * 3.0 * rn;
+    cf->near_r = 1e-6 * cs;
+    cf->margin = 0.25 * cs + 0.002;
+    cf->width = f.width, cf->height = f.height;
+    cf->blocks_x = (f.width + 7u) >> 3, cf->blocks_y = (f.height + 7u) >> 3;
+    cf->words_per_row = (cf->blocks_x + 31u) >> 5;
+    if ((size_t)cf->blocks_y * cf->words_per_row > CULL_MAX_WORDS) return false;
+    return true;
+}
+
+// The block masks for the n frames of a launch (see rt_cull.hpp), `*words` mask words apart, queued on the context's
+// stream ahead of the launch; *mask stays null when they get none: a parameter says so, nothing else of the context is
+// running (mode 1), the scene has boxes, the tiles do not line up with the frame's 8x8 blocks, the float DDA's drift
+// cannot be bounded tightly enough for a camera and the grid, a camera basis is degenerate, an origin is one that starts
+// the traversal outside the grid, or the grid is so large that making the masks costs more than it saves.
+int cull_masks_for(rt_ctx* c, const DevScene& s, const DevFrame* fs, uint32_t n, const ShardMap& m, const uint32_t** mask,
+                   uint32_t* words_out, bool always) {
+    *mask = nullptr;
+    if (!c->params.cull_empty_blocks || s.nb != 0 || n == 0 || n > CULL_MAX_FRAMES) return RT_OK;
+    // 1: only while earlier frames are still running. The mask is one more launch the trace has to wait for: with
+    // frames in flight that wait is hidden and the traversals it saves are time gained; a frame traced on an idle GPU
+    // waits for its few longest waves whatever the others do, and would only start later.
+    if (c->params.cull_empty_blocks == 1 && !always && !frames_in_flight(c)) return RT_OK;
+    CullFrames cfs;
+    for (uint32_t j = 0; j < n; ++j)
+        if (!cull_frame(s, fs[j], m, &cfs.f[j])) return RT_OK;
+    const CullFrame& cf = cfs.f[0];
+    const size_t words = (size_t)cf.blocks_y * cf.words_per_row, total = words * n;
 
     rt_cull* hit = nullptr;
     for (rt_cull* k : c->culls)
@@ -635,11 +645,11 @@ int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMa
         }
         hit->stream = c->stream;
     }
-    if (words * sizeof(uint32_t) > hit->buf[0].cap) {
+    if (total * sizeof(uint32_t) > hit->buf[0].cap) {
         // a larger frame on this stream: the old buffers may still be read by a launch queued before this one
         RT_HIP(c, hipStreamSynchronize(c->stream));
         for (int b = 0; b < 2; ++b) {
-            RT_HIP(c, hit->buf[b].reserve(words * sizeof(uint32_t)));
+            RT_HIP(c, hit->buf[b].reserve(total * sizeof(uint32_t)));
             RT_HIP(c, hipMemsetAsync(hit->buf[b].p, 0, hit->buf[b].cap, c->stream));
             hit->dirty[b] = 0;
         }
@@ -650,16 +660,26 @@ int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMa
         hit->dirty[fill] = 0;
     }
     hit->last_use = ++c->plan_clock;
-    hit->words = (uint32_t)words;
+    hit->words = (uint32_t)words;  // of the first frame of the launch: what rt_get_cull_stats reports
     hit->blocks = cf.blocks_x * cf.blocks_y;
-    hipLaunchKernelGGL(k_block_mask, dim3((s.n_cells + CULL_CELLS_PER_WAVE - 1u) / CULL_CELLS_PER_WAVE), dim3(64), words * sizeof(uint32_t), c->stream, s.cells, s.gx, s.gy, s.gz, s.px, s.pxy,
-                       s.bmin[0], s.bmin[1], s.bmin[2], s.cell_size, cf, hit->buf[fill].as<uint32_t>());
+    const uint32_t waves = (s.n_cells + CULL_CELLS_PER_WAVE - 1u) / CULL_CELLS_PER_WAVE;
+    if (n == 1)
+        hipLaunchKernelGGL(k_block_mask, dim3(waves), dim3(64), words * sizeof(uint32_t), c->stream, s.cells, s.gx, s.gy, s.gz, s.px,
+                           s.pxy, s.bmin[0], s.bmin[1], s.bmin[2], s.cell_size, cf, hit->buf[fill].as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_block_masks, dim3(waves, n), dim3(64), words * sizeof(uint32_t), c->stream, s.cells, s.gx, s.gy, s.gz, s.px,
+                           s.pxy, s.bmin[0], s.bmin[1], s.bmin[2], s.cell_size, cfs, hit->buf[fill].as<uint32_t>(), (uint32_t)words);
     RT_HIP(c, hipGetLastError());
-    hit->dirty[fill] = (uint32_t)words;
+    hit->dirty[fill] = (uint32_t)total;
     hit->cur = fill;
     c->last_cull = hit;
     *mask = hit->buf[fill].as<uint32_t>();
+    if (words_out) *words_out = (uint32_t)words;
     return RT_OK;
+}
+
+int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMap& m, const uint32_t** mask, bool always) {
+    return cull_masks_for(c, s, &f, 1, m, mask, nullptr, always);
 }
 
 // Kernel variants: WGSL (constant set), SHADOW / ANY, BOXES (scene has boxes), TEX (hits decided by a texture's
@@ -1667,26 +1687,34 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
     sh.box_frame_stride = c->nb * 4;
     sh.frame_pixels = stride;
     unsigned long long* st = stats ? c->stats.as<unsigned long long>() : nullptr;
+    // the frames' masks of pixel blocks that can meet geometry: the others are sky (rt_params.cull_empty_blocks)
+    const uint32_t* rmask = nullptr;
+    uint32_t rwords = 0;
+    c->last_cull = nullptr;
+    if (!stats && !wide_grid(s))
+        if (int r = cull_masks_for(c, s, fs.f, n_frames, m, &rmask, &rwords, false)) return r;
     const dim3 grid((uint32_t)blocks, n_frames);
     const bool wgsl = c->params.wgsl_compat != 0, has_boxes = s.nb != 0;
     if (wide_grid(s)) {
-        if (wgsl) hipLaunchKernelGGL((k_render<true, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-        else hipLaunchKernelGGL((k_render<false, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        if (wgsl) hipLaunchKernelGGL((k_render<true, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+        else hipLaunchKernelGGL((k_render<false, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
     } else if (c->tex_mode != 0) {  // materials name textures: the general kernel with the material path
-        if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-        else if (wgsl) hipLaunchKernelGGL((k_render<true, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-        else if (has_boxes) hipLaunchKernelGGL((k_render<false, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-        else hipLaunchKernelGGL((k_render<false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+        else if (wgsl) hipLaunchKernelGGL((k_render<true, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+        else if (has_boxes) hipLaunchKernelGGL((k_render<false, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+        else hipLaunchKernelGGL((k_render<false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
     } else if (o.max_bounces == 1) {  // direct lighting only
-        if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-        else if (wgsl) hipLaunchKernelGGL((k_render<true, false, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-        else if (has_boxes) hipLaunchKernelGGL((k_render<false, true, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-        else hipLaunchKernelGGL((k_render<false, false, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-    } else if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-    else if (wgsl) hipLaunchKernelGGL((k_render<true, false>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-    else if (has_boxes) hipLaunchKernelGGL((k_render<false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
-    else hipLaunchKernelGGL((k_render<false, false>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st);
+        if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+        else if (wgsl) hipLaunchKernelGGL((k_render<true, false, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+        else if (has_boxes) hipLaunchKernelGGL((k_render<false, true, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+        else hipLaunchKernelGGL((k_render<false, false, false, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+    } else if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+    else if (wgsl) hipLaunchKernelGGL((k_render<true, false>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+    else if (has_boxes) hipLaunchKernelGGL((k_render<false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+    else hipLaunchKernelGGL((k_render<false, false>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
     RT_HIP(c, hipGetLastError());
+    if (c->params.cull_empty_blocks == 1 && s.nb == 0)
+        if (int r = mark_in_flight(c)) return r;
     if (host_out) RT_HIP(c, hipMemcpyAsync(out_rgba8, out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     if (stats) {
         if (int r = fetch_stats(c)) return r;

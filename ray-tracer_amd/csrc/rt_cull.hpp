@@ -75,9 +75,9 @@ __device__ inline void cull_crossing_edges(const CullFrame& cf, const double* lo
 
 constexpr uint32_t CULL_CELLS_PER_WAVE = 512;
 
-__global__ __launch_bounds__(64, 8) void k_block_mask(const uint2* __restrict__ cells, uint32_t gx, uint32_t gy, uint32_t gz,
-                                                      uint32_t px, uint32_t pxy, float bminx, float bminy, float bminz, float cs,
-                                                      CullFrame cf, uint32_t* __restrict__ mask) {
+__device__ inline void block_mask_wave(const uint2* __restrict__ cells, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t px,
+                                       uint32_t pxy, float bminx, float bminy, float bminz, float cs, const CullFrame& cf,
+                                       uint32_t* __restrict__ mask) {
     extern __shared__ uint32_t lmask[];
     __shared__ uint32_t occupied[CULL_CELLS_PER_WAVE];
     // the frame's trace waits for this kernel, and it shares its SIMDs with the previous frame's trace waves: go first
@@ -199,6 +199,23 @@ __global__ __launch_bounds__(64, 8) void k_block_mask(const uint2* __restrict__ 
         const uint32_t v = lmask[k];
         if (v) atomicOr(mask + k, v);
     }
+}
+
+__global__ __launch_bounds__(64, 8) void k_block_mask(const uint2* __restrict__ cells, uint32_t gx, uint32_t gy, uint32_t gz,
+                                                      uint32_t px, uint32_t pxy, float bminx, float bminy, float bminz, float cs,
+                                                      CullFrame cf, uint32_t* __restrict__ mask) {
+    block_mask_wave(cells, gx, gy, gz, px, pxy, bminx, bminy, bminz, cs, cf, mask);
+}
+
+// The masks of the frames of one rt_render_frames launch (blockIdx.y picks the frame), `words` mask words apart.
+constexpr uint32_t CULL_MAX_FRAMES = 16;
+struct CullFrames {
+    CullFrame f[CULL_MAX_FRAMES];
+};
+__global__ __launch_bounds__(64, 8) void k_block_masks(const uint2* __restrict__ cells, uint32_t gx, uint32_t gy, uint32_t gz,
+                                                       uint32_t px, uint32_t pxy, float bminx, float bminy, float bminz, float cs,
+                                                       CullFrames cfs, uint32_t* __restrict__ masks, uint32_t words) {
+    block_mask_wave(cells, gx, gy, gz, px, pxy, bminx, bminy, bminz, cs, cfs.f[blockIdx.y], masks + (size_t)blockIdx.y * words);
 }
 
 }  // namespace rt

@@ -58,7 +58,7 @@ __device__ inline bool near_grid_boundary(const DevScene& s, V3 pos, float thres
 // scalar registers and nothing is carried from one traversal to the next.
 template <bool WGSL, bool BOXES, bool TEX = false, bool WIDE = false, bool SINGLE = false>
 __global__ __launch_bounds__(256, SINGLE ? 8 : RT_RENDER_WAVES) void k_render(DevScene s, DevFrames fs, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
-                                                unsigned long long* stats) {
+                                                unsigned long long* stats, const uint32_t* __restrict__ cull_masks, uint32_t cull_words) {
     const DevFrame& f = fs.f[blockIdx.y];
     const float show_grid = fs.show_grid[blockIdx.y];
     s.box_frame += (size_t)blockIdx.y * sh.box_frame_stride;
@@ -74,6 +74,18 @@ __global__ __launch_bounds__(256, SINGLE ? 8 : RT_RENDER_WAVES) void k_render(De
     const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
     const bool in_tile = lx < m.tile_w && ly < m.tile_h;
     const bool live = in_tile && px < f.width && py < f.height;
+    // A clear bit in the frame's block mask (k_block_mask in rt_cull.hpp): no camera ray of this wave's 8x8 pixel block
+    // meets an occupied cell, so every pixel of it shows the sky. The same in every lane of the wave.
+    bool may_hit = true;
+    if (cull_masks) {
+        const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile % m.tiles_x) * m.tile_w >> 3) + sub_x));
+        const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile / m.tiles_x) * m.tile_h >> 3) + sub_y));
+        const uint32_t blocks_x = (f.width + 7u) >> 3, blocks_y = (f.height + 7u) >> 3;
+        if (bx < blocks_x && by < blocks_y) {
+            const uint32_t word = cull_masks[(size_t)blockIdx.y * cull_words + (size_t)by * ((blocks_x + 31u) >> 5) + (bx >> 5)];
+            may_hit = ((word >> (bx & 31u)) & 1u) != 0u;
+        }
+    }
 
     uint32_t rgba = 0;
     Counters ctr{};
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(256, SINGLE ? 8 : RT_RENDER_WAVES) void k_render(De
             const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
             HitRec h;
             counts += 1u;
-            if (!trace_ray<WGSL, false, 0, BOXES, TEX, WIDE>(s, o, rd, h, ctr)) {
+            if (!(may_hit || bounce != 0) || !trace_ray<WGSL, false, 0, BOXES, TEX, WIDE>(s, o, rd, h, ctr)) {
                 // sky (:591-596)
                 const float t = (d.y + 1.0f) * 0.5f;
                 acc = acc + mix(v3(0.3f, 0.5f, 0.7f), v3(0.5f, 0.7f, 1.0f), t) * mult;

@@ -186,3 +186,34 @@ def test_default_mode_masks_only_while_frames_are_in_flight(rt, car_xyz9):
             assert_hits_equal(os_.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want_s, "frames in flight: shadow")
     finally:
         core.close(), off.close()
+
+
+def test_pictures_with_the_mask_equal_pictures_without(rt, ob, car_xyz9):
+    """rt_render and the frame groups of rt_render_frames: a culled block is sky, byte for byte what the traversal's miss
+    gives (raytracer_unified.wgsl:591-596)."""
+    on, off = both(rt, car_xyz9)
+    try:
+        w, h = 480, 270
+        for name, pos, yaw, pitch in POSES:
+            cam = rt.Camera(pos, yaw, pitch).to_uniform(0.0, float(h))
+            for bounces, shadows in ((8, False), (1, True)):
+                a, b = on.render(cam, w, h, max_bounces=bounces, shadows=shadows), off.render(cam, w, h, max_bounces=bounces, shadows=shadows)
+                assert on.cull_stats()[0] > 0 and off.cull_stats() == (0, 0)
+                assert np.array_equal(a, b), f"{name}: picture, {bounces} bounces"
+        # sixteen frames of a camera path in one launch, every frame its own mask; shards; the three-byte format
+        cams = [rt.Camera((2500 - 150 * k, 900 - 40 * k, 2600 - 160 * k), 3.9 + 0.01 * k, -0.25).to_uniform(0.1 * k, float(h)) for k in range(16)]
+        for shard in (None, rt.RtShard(32, 32, 1, 3), rt.RtShard(64, 40, 0, 2)):
+            for rgb8 in (False, True):
+                a = on.render_frames(cams, w, h, shard=shard, max_bounces=1, shadows=True, rgb8=rgb8)
+                b = off.render_frames(cams, w, h, shard=shard, max_bounces=1, shadows=True, rgb8=rgb8)
+                assert on.cull_stats()[0] > 0
+                assert np.array_equal(a, b), f"frame group, shard {shard is not None}, rgb8 {rgb8}"
+        frames = on.render_frames(cams, w, h, max_bounces=1, shadows=True)
+        assert not np.array_equal(frames[0], frames[15])  # the path moves
+        # against the oracle, one picture
+        scene = ob.Scene(None, ob.triangles_from_xyz9(car_xyz9))
+        cam = rt.Camera((2500, 900, 2600), 3.9, -0.25).to_uniform(0.0, float(h))
+        want, _ = ob.render(scene, ocam(ob, cam), w, h, params=oparams(ob, on.params), max_bounces=8)
+        assert np.array_equal(on.render(cam, w, h), want)
+    finally:
+        on.close(), off.close()

@@ -98,10 +98,11 @@ typedef struct rt_params {
                                          and mark the 8x8 pixel blocks they can be seen through; a block left unmarked
                                          has rays that meet no candidate list, so its 64 records are written as misses
                                          without a traversal. The same answers bit for bit.
-                                         0: never. 1 (default): while earlier frames of this context are still running on
-                                         the GPU (frames in flight: the extra launch is hidden and the saved traversals
-                                         are time gained; a lone frame on an idle GPU waits for its longest waves either
-                                         way and would only start later). 2: always.
+                                         0: never. 1 (default): where the extra launch is hidden - while frames of this
+                                         context are still running on two or more other streams (three frames in flight),
+                                         or for four or more frames in one rt_render_frames call; a lone frame on an
+                                         idle GPU waits for its longest waves either way and would only start later,
+                                         and with two frames in flight the launch costs what the mask saves. 2: always.
                                          Applies when tiles are multiples of 8 pixels, the grid has at most 2^21 cells, the
                                          frame at most 2^19 blocks, and no plan of expensive blocks is kept; otherwise
                                          every ray walks the grid. No reference counterpart */

@@ -516,12 +516,14 @@ static bool invert_columns(const double c0[3], const double c1[3], const double 
     return true;
 }
 
-// True while a frame traced through this context may still be running on any of its streams.
-static bool frames_in_flight(rt_ctx* c) {
+// On how many of the context's OTHER streams a traced frame may still be running (a frame on the current stream does
+// not overlap the one being queued behind it).
+static uint32_t frames_in_flight(rt_ctx* c) {
+    uint32_t n = 0;
     for (const rt_inflight& e : c->inflight)
-        if (hipEventQuery(e.done) == hipErrorNotReady) return true;
+        if (e.stream != c->stream && hipEventQuery(e.done) == hipErrorNotReady) ++n;
     (void)hipGetLastError();
-    return false;
+    return n;
 }
 
 // After a trace launch on the context's stream: the event that frames_in_flight() asks.
@@ -621,10 +623,12 @@ int cull_masks_for(rt_ctx* c, const DevScene& s, const DevFrame* fs, uint32_t n,
                    uint32_t* words_out, bool always) {
     *mask = nullptr;
     if (!c->params.cull_empty_blocks || s.nb != 0 || n == 0 || n > CULL_MAX_FRAMES) return RT_OK;
-    // 1: only while earlier frames are still running. The mask is one more launch the trace has to wait for: with
-    // frames in flight that wait is hidden and the traversals it saves are time gained; a frame traced on an idle GPU
+    // 1: only where it pays. The mask is one more launch the trace has to wait for, 9 us alone and 20-30 us beside other
+    // streams' work. A group of frames in one launch shares that wait; with frames running on two or more other streams
+    // it is hidden and the traversals saved are time gained (three in flight: 67 -> 62 us per frame); with one other
+    // stream it is break-even for hit records and a loss for the shaded picture, and a frame traced on an idle GPU
     // waits for its few longest waves whatever the others do, and would only start later.
-    if (c->params.cull_empty_blocks == 1 && !always && !frames_in_flight(c)) return RT_OK;
+    if (c->params.cull_empty_blocks == 1 && !always && n < 4 && frames_in_flight(c) < 2) return RT_OK;
     CullFrames cfs;
     for (uint32_t j = 0; j < n; ++j)
         if (!cull_frame(s, fs[j], m, &cfs.f[j])) return RT_OK;

@@ -153,7 +153,7 @@ def test_degenerate_camera_basis_gets_no_mask(rt, car_xyz9):
         on.close(), off.close()
 
 
-def test_default_mode_masks_only_while_frames_are_in_flight(rt, car_xyz9):
+def test_default_mode_masks_only_with_three_frames_in_flight_or_frame_groups(rt, car_xyz9):
     import torch
     core = rt.TraceCore(0, rt.default_params())  # cull_empty_blocks = 1
     off = rt.TraceCore(0, rt.default_params(cull_empty_blocks=0))
@@ -170,20 +170,34 @@ def test_default_mode_masks_only_while_frames_are_in_flight(rt, car_xyz9):
             assert core.cull_stats() == (0, 0)
             assert_hits_equal(p, want_p, "lone frame: primary")
             assert_hits_equal(s, want_s, "lone frame: shadow")
-        # frames queued behind each other on two streams: those that find an earlier one still running get a mask
-        streams = [torch.cuda.Stream() for _ in range(2)]
+        # two frames in flight (two streams): the launch would cost what the mask saves, so none is made
+        streams = [torch.cuda.Stream() for _ in range(3)]
         outs = [(torch.empty((w * h, 2), dtype=torch.int32, device="cuda"), torch.empty((w * h, 2), dtype=torch.int32, device="cuda"))
-                for _ in range(2)]
-        masked = 0
-        for k in range(24):
+                for _ in range(3)]
+        for k in range(12):
             core.set_stream(streams[k % 2].cuda_stream)
             core.trace_primary(cam, w, h, out_primary=outs[k % 2][0], out_shadow=outs[k % 2][1])
+        assert core.cull_stats() == (0, 0)
+        torch.cuda.synchronize()
+        # three in flight: a frame that finds the two other streams busy gets a mask
+        for k in range(36):
+            core.set_stream(streams[k % 3].cuda_stream)
+            core.trace_primary(cam, w, h, out_primary=outs[k % 3][0], out_shadow=outs[k % 3][1])
         masked = core.cull_stats()  # of the last launch; waits for its stream
         torch.cuda.synchronize()
         assert masked[0] == -(-w // 8) * -(-h // 8) and 0 < masked[1] < masked[0], masked
         for op, os_ in outs:
             assert_hits_equal(op.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want_p, "frames in flight: primary")
             assert_hits_equal(os_.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want_s, "frames in flight: shadow")
+        # a group of frames in one launch shares the mask launch: masks even on an idle GPU; fewer than four frames: none
+        core.set_stream(streams[0].cuda_stream)
+        cams = [rt.Camera((2500 - 100 * k, 900, 2600), 3.9, -0.25).to_uniform(0.0, float(h)) for k in range(4)]
+        a = core.render_frames(cams, w, h, max_bounces=1, shadows=True)
+        assert core.cull_stats()[0] > 0
+        b = off.render_frames(cams, w, h, max_bounces=1, shadows=True)
+        assert np.array_equal(a, b)
+        core.render_frames(cams[:3], w, h, max_bounces=1, shadows=True)
+        assert core.cull_stats() == (0, 0)
     finally:
         core.close(), off.close()
 

@@ -6,11 +6,11 @@ import ray_tracer_amd as rt
 xyz9 = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/car_tris.npy"))
 W, H = 1920, 1080
 NS = int(os.environ.get("RT_STREAMS", "3"))
-for cull in (0, 1):
+streams = [torch.cuda.Stream() for _ in range(NS)]  # the same streams (hardware queues) for every mode
+for cull in (0, 1, 2):
     core = rt.TraceCore(0, rt.default_params(cull_empty_blocks=cull))
     core.set_scene(None, rt.triangles_from_xyz9(xyz9)); core.build_grid()
     cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
-    streams = [torch.cuda.Stream() for _ in range(NS)]
     bufs = [(torch.empty((W*H, 2), dtype=torch.int32, device="cuda"), torch.empty((W*H, 2), dtype=torch.int32, device="cuda")) for _ in range(NS)]
     def frames(n):
         for k in range(n):

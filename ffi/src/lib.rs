@@ -54,6 +54,9 @@ extern "C" {
     pub fn rt_get_trace_refs(ctx: *mut RtCtx, n_trace_refs: *mut u32) -> c_int;
     /// What the last planned `rt_trace_primary` launch decided for the next one (params.heavy_block_threshold).
     pub fn rt_get_heavy_blocks(ctx: *mut RtCtx, n_heavy: *mut u32, n_early: *mut u32, threshold_us: *mut u32) -> c_int;
+    /// `rt_trace_primary` for up to 16 consecutive frames of a camera path in one launch.
+    pub fn rt_trace_primary_frames(ctx: *mut RtCtx, cameras: *const c_void, n_frames: u32, width: u32, height: u32,
+                                   shard: *const c_void, out_primary: *mut c_void, out_shadow: *mut c_void, frame_stride: usize) -> c_int;
     /// Frame blocks of the last `rt_trace_primary` launch and how many its block mask kept (params.cull_empty_blocks).
     pub fn rt_get_cull_stats(ctx: *mut RtCtx, blocks_total: *mut u32, blocks_kept: *mut u32) -> c_int;
     pub fn rt_set_textures(ctx: *mut RtCtx, textures: *const RtTexture, n: u32) -> c_int;

@@ -249,6 +249,15 @@ int rt_update_vertices(rt_ctx* ctx, const float* xyz9, uint32_t first, uint32_t 
 int rt_trace_primary(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
                      const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow);
 
+/* rt_trace_primary for up to 16 consecutive frames of a camera path in one call (the reference dispatches once per frame,
+ * src/renderer.rs:857-868: no counterpart; for renderers that trace ahead of display or several views of a scene).
+ * cameras[j] is frame j; its records are written frame_stride records after frame j-1's (0 = packed: one frame's worth).
+ * Triangle-only scenes with device outputs go out as ONE launch in which a frame's last waves overlap the next frame's
+ * bulk (and one block-mask launch for the group, params.cull_empty_blocks); every other case is traced frame by frame.
+ * The same records as n_frames calls of rt_trace_primary. */
+int rt_trace_primary_frames(rt_ctx* ctx, const CameraUniform* cameras, uint32_t n_frames, uint32_t width, uint32_t height,
+                            const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow, size_t frame_stride);
+
 /* rt_trace_primary for callers that cannot allocate device memory while they run: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc. No counterpart in the reference. Same arguments, same
  * results; it calls no hipMalloc / hipFree and no allocating routine. The one buffer a trace needs beyond its inputs

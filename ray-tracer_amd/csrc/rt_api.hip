@@ -1356,6 +1356,72 @@ extern "C" int rt_trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t wi
     return trace_primary<false>(c, cam, width, height, shard, out_primary, out_shadow, "rt_trace_primary");
 }
 
+// Up to MAX_FRAMES_PER_LAUNCH frames of a camera path in one launch. Frame j's records start frame_stride records after
+// frame j-1's (0 = packed). Triangle-only scenes without counters, textured alpha or a plan of expensive blocks take
+// k_trace_primary_frames; anything else is traced frame by frame through rt_trace_primary, with the same records.
+extern "C" int rt_trace_primary_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n_frames, uint32_t width, uint32_t height,
+                                       const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow, size_t frame_stride) {
+    const char* who = "rt_trace_primary_frames";
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "%s: no grid (call rt_build_grid or rt_set_grid_*)", who);
+    if (!cams || !out_primary) return fail(c, RT_ERR_INVALID, "%s: NULL camera or output", who);
+    if (!width || !height) return fail(c, RT_ERR_INVALID, "%s: empty frame", who);
+    if (n_frames == 0) return RT_OK;
+    if (n_frames > MAX_FRAMES_PER_LAUNCH)
+        return fail(c, RT_ERR_LIMIT, "%s: %u frames in one call (max %u)", who, n_frames, MAX_FRAMES_PER_LAUNCH);
+    ShardMap m;
+    if (int r = make_shard(c, width, height, shard, &m, who)) return r;
+    const size_t n_frame = (size_t)m.n_local * m.tile_w * m.tile_h;
+    if (n_frame == 0) return RT_OK;
+    if (frame_stride && frame_stride < n_frame)
+        return fail(c, RT_ERR_INVALID, "%s: frame_stride %zu smaller than the %zu records of a frame", who, frame_stride, n_frame);
+    const size_t stride = frame_stride ? frame_stride : n_frame;
+    const uint64_t blocks = (uint64_t)m.n_local * ((m.sub_x + 1) / 2) * ((m.sub_y + 1) / 2);
+    if (blocks > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "%s: frame too large", who);
+    const DevScene s = make_scene(c);
+    const bool host_out = !is_device_ptr(out_primary) || (out_shadow && !is_device_ptr(out_shadow));
+    const bool grouped = !c->params.collect_stats && c->grid_nb == 0 && c->tex_mode != 2 && !wide_grid(s) &&
+                         !c->params.heavy_block_threshold && !host_out && n_frames > 1;
+    if (!grouped) {
+        for (uint32_t j = 0; j < n_frames; ++j)
+            if (int r = trace_primary<false>(c, cams + j, width, height, shard, out_primary + j * stride,
+                                             out_shadow ? out_shadow + j * stride : nullptr, who))
+                return r;
+        return RT_OK;
+    }
+    DevFrames fs;
+    memset(&fs, 0, sizeof(fs));
+    for (uint32_t j = 0; j < n_frames; ++j) fs.f[j] = make_frame(c, cams + j, width, height);
+    const uint32_t* mask = nullptr;
+    uint32_t words = 0;
+    c->last_cull = nullptr;
+    if (int r = cull_masks_for(c, s, fs.f, n_frames, m, &mask, &words, false)) return r;
+    uint32_t* zero = nullptr;
+    uint32_t zero_words = 0;
+    if (mask) {
+        rt_cull* k = c->last_cull;
+        zero = k->buf[k->cur ^ 1].as<uint32_t>();
+        zero_words = k->dirty[k->cur ^ 1];
+        k->dirty[k->cur ^ 1] = 0;
+    }
+    uint2* op = reinterpret_cast<uint2*>(out_primary);
+    uint2* os = reinterpret_cast<uint2*>(out_shadow);
+    const dim3 grid((uint32_t)blocks, n_frames);
+    const unsigned long long fstride = stride;
+    const bool wgsl = c->params.wgsl_compat != 0;
+    if (out_shadow) {
+        if (wgsl) hipLaunchKernelGGL((k_trace_primary_frames<true, true>), grid, dim3(256), 0, c->stream, s, fs, m, op, os, mask, zero, zero_words, words, fstride);
+        else hipLaunchKernelGGL((k_trace_primary_frames<false, true>), grid, dim3(256), 0, c->stream, s, fs, m, op, os, mask, zero, zero_words, words, fstride);
+    } else {
+        if (wgsl) hipLaunchKernelGGL((k_trace_primary_frames<true, false>), grid, dim3(256), 0, c->stream, s, fs, m, op, os, mask, zero, zero_words, words, fstride);
+        else hipLaunchKernelGGL((k_trace_primary_frames<false, false>), grid, dim3(256), 0, c->stream, s, fs, m, op, os, mask, zero, zero_words, words, fstride);
+    }
+    RT_HIP(c, hipGetLastError());
+    if (c->params.cull_empty_blocks == 1)
+        if (int r = mark_in_flight(c)) return r;
+    return RT_OK;
+}
+
 // Calls no hipMalloc / hipFree and no routine that allocates: see the scratch array at the top of this file.
 extern "C" int rt_trace_primary_noalloc(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height,
                                         const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow) {

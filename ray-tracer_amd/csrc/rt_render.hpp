@@ -29,13 +29,6 @@ struct DevShade {
     size_t frame_pixels;        // output records per frame
 };
 
-// Frames of one launch (blockIdx.y picks one): consecutive frames of a camera path rendered together, so that the
-// long dependent chains of the few expensive pixel blocks of one frame overlap the bulk of the others.
-constexpr uint32_t MAX_FRAMES_PER_LAUNCH = 16;
-struct DevFrames {
-    DevFrame f[MAX_FRAMES_PER_LAUNCH];
-    float show_grid[MAX_FRAMES_PER_LAUNCH];
-};
 
 __device__ inline uint32_t unorm8(float c) {
     float x = fminf(fmaxf(c, 0.0f), 1.0f);  // fmaxf(NaN, 0) = 0

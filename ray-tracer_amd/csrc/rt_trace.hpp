@@ -81,6 +81,14 @@ struct DevFrame {
     uint32_t width, height;
 };
 
+// Frames of one launch (blockIdx.y picks one): consecutive frames of a camera path traced or rendered together, so that
+// the long dependent chains of the few expensive pixel blocks of one frame overlap the bulk of the others.
+constexpr uint32_t MAX_FRAMES_PER_LAUNCH = 16;
+struct DevFrames {
+    DevFrame f[MAX_FRAMES_PER_LAUNCH];
+    float show_grid[MAX_FRAMES_PER_LAUNCH];
+};
+
 struct ShardMap {
     uint32_t tile_w, tile_h, first, stride, count, tiles_x, tiles_y, n_tiles, n_local;
     uint32_t sub_x, sub_y;  // 8x8 sub-tiles per tile
@@ -599,6 +607,20 @@ struct PrimaryArgs {
     uint32_t cull_zero_words;
 };
 
+// The arguments of k_trace_primary_frames as the kernel-argument segment lays them out.
+struct PrimaryFramesArgs {
+    DevScene s;
+    DevFrames fs;
+    ShardMap m;
+    uint2* out_p;
+    uint2* out_s;
+    const uint32_t* cull_mask;  // the frames' block masks, cull_words words apart, or null
+    uint32_t* cull_zero;
+    uint32_t cull_zero_words;
+    uint32_t cull_words;
+    unsigned long long frame_stride;  // hit records between the frames of an output array
+};
+
 // A word / a pointer of the kernel-argument segment, read where it is needed (see late_shadow_dir).
 __device__ inline uint32_t late_arg_u32(uint32_t byte_offset) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -619,6 +641,16 @@ __device__ inline const uint32_t* late_arg_cptr(uint32_t byte_offset) {
     return nullptr;
 #endif
 }
+__device__ inline unsigned long long late_arg_u64(uint32_t byte_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) uint8_t* KernArg;
+    KernArg base = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    return *reinterpret_cast<const __attribute__((address_space(4))) unsigned long long*>(base + byte_offset);
+#else
+    return byte_offset;
+#endif
+}
 __device__ inline uint2* late_arg_ptr(uint32_t byte_offset) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(4))) uint8_t* KernArg;
@@ -633,13 +665,13 @@ __device__ inline uint2* late_arg_ptr(uint32_t byte_offset) {
 // The shadow ray's direction record, read from the kernel-argument segment where it is first needed instead of at
 // the start of the kernel: fifteen scalar registers that would otherwise sit through the whole primary traversal,
 // and push the kernel over the 80 scalar registers that eight waves per SIMD leave each wave.
-__device__ inline RayDir late_shadow_dir() {
+__device__ inline RayDir late_shadow_dir(uint32_t frame_byte_offset) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(4))) uint8_t* KernArg;
     KernArg base = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(base));  // the loads below stay below
     const __attribute__((address_space(4))) uint32_t* w = reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(
-        base + offsetof(PrimaryArgs, f) + offsetof(DevFrame, shadow));
+        base + frame_byte_offset + offsetof(DevFrame, shadow));
     RayDir r;
     r.d = v3(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]));
     r.inv = v3(__uint_as_float(w[3]), __uint_as_float(w[4]), __uint_as_float(w[5]));
@@ -655,9 +687,18 @@ static_assert(sizeof(RayDir) == 60 && offsetof(RayDir, sx) == 36 && offsetof(Ray
 
 // LATE: the kernel's arguments are exactly PrimaryArgs' members in that order, and what the epilogue needs of them is
 // read again there instead of being kept in scalar registers through both traversals.
-template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX, bool WIDE, bool LATE = false>
+// FRAMES (with LATE): the kernel's arguments are PrimaryFramesArgs', blockIdx.y picks the frame.
+template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX, bool WIDE, bool LATE = false, bool FRAMES = false>
 __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* __restrict__ out_p,
                                            uint2* __restrict__ out_s, unsigned long long* stats, const uint32_t* cull_mask = nullptr) {
+    static_assert(!FRAMES || LATE, "the frames kernel reads its arguments late");
+    constexpr uint32_t A_M = FRAMES ? offsetof(PrimaryFramesArgs, m) : offsetof(PrimaryArgs, m);
+    constexpr uint32_t A_OUT_P = FRAMES ? offsetof(PrimaryFramesArgs, out_p) : offsetof(PrimaryArgs, out_p);
+    constexpr uint32_t A_OUT_S = FRAMES ? offsetof(PrimaryFramesArgs, out_s) : offsetof(PrimaryArgs, out_s);
+    constexpr uint32_t A_MASK = FRAMES ? offsetof(PrimaryFramesArgs, cull_mask) : offsetof(PrimaryArgs, cull_mask);
+    const uint32_t frame_no = FRAMES ? blockIdx.y : 0u;
+    const uint32_t a_frame = FRAMES ? (uint32_t)offsetof(PrimaryFramesArgs, fs) + frame_no * (uint32_t)sizeof(DevFrame)
+                                    : (uint32_t)offsetof(PrimaryArgs, f);
     const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
     const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;  // 16x16 blocks per tile
     const uint32_t blk_per_tile = blk_x * blk_y;
@@ -674,7 +715,8 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
         // A clear bit in the frame's block mask (k_block_mask in rt_cull.hpp): no primary ray of this wave's 8x8 pixel
         // block meets an occupied cell, so all 64 records are misses. Tiles are whole multiples of 8 pixels when a mask
         // is given, so the wave's block is one block of the frame's 8x8 raster; everything here is the same in every lane.
-        const uint32_t* mask = LATE ? late_arg_cptr(offsetof(PrimaryArgs, cull_mask)) : cull_mask;
+        const uint32_t* mask = LATE ? late_arg_cptr(A_MASK) : cull_mask;
+        if (FRAMES && mask) mask += (size_t)frame_no * late_arg_u32(offsetof(PrimaryFramesArgs, cull_words));
         if (mask) {
             const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile % m.tiles_x) * m.tile_w >> 3) + sub_x));
             const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile / m.tiles_x) * m.tile_h >> 3) + sub_y));
@@ -707,7 +749,7 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
                 HitRec oh;
                 n_rays++;
                 n_sr++;
-                const RayDir to_light = late_shadow_dir();
+                const RayDir to_light = late_shadow_dir(a_frame);
                 if (trace_ray<WGSL, true, STATS, BOXES, TEX, WIDE>(s, so, to_light, oh, ctr)) {
                     n_sh++;
                     sh = make_uint2(oh.id, __float_as_uint(oh.t));
@@ -717,11 +759,12 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
     }
     if (in_tile) {
         if (LATE) {
-            const uint32_t tw = late_arg_u32(offsetof(PrimaryArgs, m) + offsetof(ShardMap, tile_w));
-            const uint32_t th = late_arg_u32(offsetof(PrimaryArgs, m) + offsetof(ShardMap, tile_h));
-            const size_t oi = (size_t)lt * tw * th + (size_t)ly * tw + lx;
-            late_arg_ptr(offsetof(PrimaryArgs, out_p))[oi] = ph;
-            if (SHADOW) late_arg_ptr(offsetof(PrimaryArgs, out_s))[oi] = sh;
+            const uint32_t tw = late_arg_u32(A_M + offsetof(ShardMap, tile_w));
+            const uint32_t th = late_arg_u32(A_M + offsetof(ShardMap, tile_h));
+            size_t oi = (size_t)lt * tw * th + (size_t)ly * tw + lx;
+            if (FRAMES) oi += (size_t)frame_no * late_arg_u64(offsetof(PrimaryFramesArgs, frame_stride));
+            late_arg_ptr(A_OUT_P)[oi] = ph;
+            if (SHADOW) late_arg_ptr(A_OUT_S)[oi] = sh;
         } else {
             const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
             out_p[oi] = ph;
@@ -747,6 +790,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_tr
     if (cull_zero)
         for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < cull_zero_words; k += gridDim.x * 256u) cull_zero[k] = 0u;
     trace_primary_block<WGSL, SHADOW, 0, false, false, false, true>(s, f, m, out_p, out_s, nullptr);
+}
+
+// The same for up to MAX_FRAMES_PER_LAUNCH frames of a camera path in one launch (blockIdx.y = frame): one launch and
+// one mask launch for all of them, and the tail of a frame overlaps the bulk of the next without a second stream.
+template <bool WGSL, bool SHADOW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_trace_primary_frames(
+    DevScene s, DevFrames fs, ShardMap m, uint2* __restrict__ out_p, uint2* __restrict__ out_s, const uint32_t* __restrict__ cull_mask,
+    uint32_t* __restrict__ cull_zero, uint32_t cull_zero_words, uint32_t cull_words, unsigned long long frame_stride) {
+    if (cull_zero)
+        for (uint32_t k = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x; k < cull_zero_words; k += gridDim.x * gridDim.y * 256u)
+            cull_zero[k] = 0u;
+    trace_primary_block<WGSL, SHADOW, 0, false, false, false, true, true>(s, fs.f[blockIdx.y], m, out_p, out_s, nullptr);
 }
 
 // Pixel blocks that are expensive: a plan made by one launch for the next one of the same frame shape.
@@ -908,7 +963,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_tr
                 if (dot(n, d) > 0.0f) n = neg(n);
                 const V3 so = pos + n * f.shadow_offset;
                 HitRec oh;
-                const RayDir to_light = late_shadow_dir();
+                const RayDir to_light = late_shadow_dir((uint32_t)offsetof(PrimaryArgs, f));
                 if (trace_ray<WGSL, true, 0, false, false, false, TRACE_QUAD>(s, so, to_light, oh, ctr, qstep))
                     sh = make_uint2(oh.id, __float_as_uint(oh.t));
             }

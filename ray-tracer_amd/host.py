@@ -319,6 +319,21 @@ class TraceCore:
                                           _ptr(out_shadow) if shadow else None))
         return out_primary, (out_shadow if shadow else None)
 
+    def trace_primary_frames(self, cams, width, height, shard=None, shadow=True, out_primary=None, out_shadow=None, frame_stride=0):
+        """rt_trace_primary_frames: up to 16 consecutive frames in one call. Returns (primary, shadow|None), numpy
+        HIT_DTYPE arrays of shape (n_frames, n_records) unless torch CUDA tensors / device pointers are passed."""
+        n = frame_stride or shard_pixels(width, height, shard)
+        arr = (CameraUniform * len(cams))()
+        for j, cam in enumerate(cams):
+            C.memmove(C.byref(arr, j * C.sizeof(CameraUniform)), C.byref(cam), C.sizeof(CameraUniform))
+        if out_primary is None:
+            out_primary = np.empty((len(cams), n), HIT_DTYPE)
+        if shadow and out_shadow is None:
+            out_shadow = np.empty((len(cams), n), HIT_DTYPE)
+        self._ck(self._L.rt_trace_primary_frames(self._h, arr, len(cams), width, height, _ref(shard, RtShard), _ptr(out_primary),
+                                                 _ptr(out_shadow) if shadow else None, frame_stride))
+        return out_primary, (out_shadow if shadow else None)
+
     def trace_primary_noalloc(self, cam, width, height, out_primary, out_shadow=None, shard=None):
         """rt_trace_primary_noalloc: the same trace without any device allocation; outputs must be device memory
         (torch CUDA tensors or raw device pointers)."""

@@ -231,3 +231,65 @@ def test_pictures_with_the_mask_equal_pictures_without(rt, ob, car_xyz9):
         assert np.array_equal(on.render(cam, w, h), want)
     finally:
         on.close(), off.close()
+
+
+def test_frames_of_a_camera_path_in_one_launch(rt, ob, car_xyz9):
+    """rt_trace_primary_frames == rt_trace_primary frame by frame: device outputs take the one-launch kernel (with and without
+    block masks, shards, a frame stride, primary only), host outputs and scenes with boxes the frame-by-frame route."""
+    import torch
+    w, h = 333, 187
+    cams = [rt.Camera((2500 - 150 * k, 900 - 40 * k, 2600 - 160 * k), 3.9 + 0.01 * k, -0.25).to_uniform(0.1 * k, float(h)) for k in range(16)]
+    for cull in (2, 1, 0):
+        core = rt.TraceCore(0, rt.default_params(cull_empty_blocks=cull))
+        try:
+            core.set_scene(None, rt.triangles_from_xyz9(car_xyz9))
+            core.build_grid()
+            for shard in (None, rt.RtShard(32, 32, 1, 3), rt.RtShard(30, 20, 0, 2)):
+                n = rt.shard_pixels(w, h, shard) if hasattr(rt, "shard_pixels") else None
+                want = [core.trace_primary(cam, w, h, shard=shard) for cam in cams]
+                n = len(want[0][0])
+                for stride in (0, n + 37):
+                    fs = stride or n
+                    dp = torch.full((16 * fs, 2), -7, dtype=torch.int32, device="cuda")
+                    ds = torch.full((16 * fs, 2), -7, dtype=torch.int32, device="cuda")
+                    core.trace_primary_frames(cams, w, h, shard=shard, out_primary=dp, out_shadow=ds, frame_stride=stride)
+                    core.sync()
+                    gp = dp.cpu().numpy().view(rt.HIT_DTYPE).reshape(16, fs)
+                    gs = ds.cpu().numpy().view(rt.HIT_DTYPE).reshape(16, fs)
+                    for k in range(16):
+                        assert_hits_equal(gp[k, :n], want[k][0], f"cull {cull} frame {k} primary (stride {stride})")
+                        assert_hits_equal(gs[k, :n], want[k][1], f"cull {cull} frame {k} shadow (stride {stride})")
+                    if stride:
+                        assert (gp[:, n:]["id"].view(np.int32) == -7).all()  # the gap between frames is not written
+                    if cull == 2 and (shard is None or shard.tile_w % 8 == 0):
+                        assert core.cull_stats()[0] > 0
+            # primary only, five frames, host arrays (the frame-by-frame route)
+            hp, hs = core.trace_primary_frames(cams[:5], w, h, shadow=False)
+            assert hs is None
+            for k in range(5):
+                assert_hits_equal(hp[k], core.trace_primary(cams[k], w, h, shadow=False)[0], f"host output frame {k}")
+            dp = torch.empty((5 * w * h, 2), dtype=torch.int32, device="cuda")
+            core.trace_primary_frames(cams[:5], w, h, shadow=False, out_primary=dp)
+            core.sync()
+            gp = dp.cpu().numpy().view(rt.HIT_DTYPE).reshape(5, w * h)
+            for k in range(5):
+                assert_hits_equal(gp[k], hp[k], f"primary only, device output, frame {k}")
+        finally:
+            core.close()
+    # against the oracle, one group
+    core = rt.TraceCore(0, rt.default_params(cull_empty_blocks=2))
+    try:
+        core.set_scene(None, rt.triangles_from_xyz9(car_xyz9))
+        core.build_grid()
+        scene = ob.Scene(None, ob.triangles_from_xyz9(car_xyz9))
+        dp = torch.empty((4 * w * h, 2), dtype=torch.int32, device="cuda")
+        ds = torch.empty_like(dp)
+        core.trace_primary_frames(cams[:4], w, h, out_primary=dp, out_shadow=ds)
+        core.sync()
+        gp, gs = (t.cpu().numpy().view(rt.HIT_DTYPE).reshape(4, w * h) for t in (dp, ds))
+        for k in range(4):
+            op, os_, _ = ob.trace_primary(scene, ocam(ob, cams[k]), w, h, params=oparams(ob, core.params), n_threads=8)
+            assert_hits_equal(gp[k], op, f"oracle frame {k} primary")
+            assert_hits_equal(gs[k], os_, f"oracle frame {k} shadow")
+    finally:
+        core.close()

@@ -260,6 +260,16 @@ def main():
 
     import torch.distributed as dist
 
+    # The contract is ONE line on stdout. Libraries print there too (RCCL writes a version banner when its first
+    # communicator is made), so everything else this process writes to file descriptor 1 goes to stderr, and the JSON
+    # line is written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real_stdout, (line + "\n").encode())
+
     if os.environ.get("RT_BENCH_WATCHDOG"):  # development: dump every thread's stack if the run takes this many seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
@@ -294,8 +304,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     if os.environ.get("RT_BENCH_LEG") == "streaming" and not multi:  # development / profiling: the second leg alone
-        print(json.dumps({"metric": "streaming leg only", "n_gpus": 1,
-                          "roofline_streaming": streaming_leg(rt, dev, int(os.environ.get("RT_BENCH_STREAM_STEPS", "20")), 3)}), flush=True)
+        emit(json.dumps({"metric": "streaming leg only", "n_gpus": 1,
+                         "roofline_streaming": streaming_leg(rt, dev, int(os.environ.get("RT_BENCH_STREAM_STEPS", "20")), 3)}))
         return
 
     xyz9 = None
@@ -551,7 +561,7 @@ def main():
                 out["roofline_streaming"] = streaming_leg(rt, dev, int(os.environ.get("RT_BENCH_STREAM_STEPS", "20")), 3)
             if not args.no_cpu_baseline and xyz9 is not None:
                 out["cpu_baseline"] = cpu_baseline(xyz9, WIDTH, HEIGHT)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if core._h:
         core.close()
     if multi:

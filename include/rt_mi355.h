@@ -104,7 +104,7 @@ typedef struct rt_params {
                                          idle GPU waits for its longest waves either way and would only start later,
                                          and with two frames in flight the launch costs what the mask saves. 2: always.
                                          Applies when tiles are multiples of 8 pixels, the grid has at most 2^21 cells, the
-                                         frame at most 2^19 blocks, and no plan of expensive blocks is kept; otherwise
+                                         frame's mask at most 15 360 words (e.g. 7680 x 4096 pixels), and no plan of expensive blocks is kept; otherwise
                                          every ray walks the grid. No reference counterpart */
 } rt_params;
 

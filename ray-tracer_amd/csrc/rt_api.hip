@@ -499,7 +499,9 @@ BlockPlan make_block_plan(const rt_plan* p, uint32_t threshold_us) {
     return b;
 }
 
-constexpr size_t CULL_MAX_WORDS = 16384;      // mask words a workgroup of k_block_mask can hold in LDS (an 8K frame: 16 200)
+// mask words a wave of k_block_mask can hold in LDS beside its list of occupied cells (64 KB a workgroup): frames of up
+// to 491 520 blocks of 8x8 pixels, e.g. 7680 x 4096; a 7680 x 4320 frame (16 200 words) gets no mask
+constexpr size_t CULL_MAX_WORDS = 15360;
 constexpr uint32_t CULL_MAX_CELLS = 1u << 21;  // beyond this many grid cells a frame's mask costs more than it saves
 
 // Inverse of the 3x3 matrix with columns c0, c1, c2, as rows; false when it is singular (or not finite).

@@ -293,3 +293,25 @@ def test_frames_of_a_camera_path_in_one_launch(rt, ob, car_xyz9):
             assert_hits_equal(gs[k], os_, f"oracle frame {k} shadow")
     finally:
         core.close()
+
+
+def test_large_frames(rt, car_xyz9):
+    """3840x2160 has a mask (4 050 words); 7680x4320 would need more LDS than a wave of the mask kernel may take and is
+    traced without one. Sampled rows of the frames with the mask against without."""
+    import torch
+    on, off = both(rt, car_xyz9)
+    try:
+        for (w, h, masked) in ((3840, 2160, True), (7680, 4320, False)):
+            cam = rt.Camera((2500, 900, 2600), 3.9, -0.25).to_uniform(0.0, float(h))
+            outs = []
+            for c in (on, off):
+                p = torch.empty((w * h, 2), dtype=torch.int32, device="cuda")
+                s = torch.empty_like(p)
+                c.trace_primary(cam, w, h, out_primary=p, out_shadow=s)
+                c.sync()
+                outs.append((p, s))
+            assert (on.cull_stats()[0] > 0) == masked, on.cull_stats()
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), f"{w}x{h}"
+            del outs
+    finally:
+        on.close(), off.close()

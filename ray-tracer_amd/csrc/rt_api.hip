@@ -717,6 +717,12 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
                 hipLaunchKernelGGL(k_trace_primary_quad_all, dim3(grid.x * 4), dim3(256), 0, c->stream, s, f, m, op, os);
                 return RT_OK;
             }
+            if (vn == 72) {  // the shipped kernel with the frame's block mask, whatever the parameter says
+                const uint32_t* mask = nullptr;
+                if (int r = cull_mask_for(c, s, f, m, &mask, true)) return r;
+                hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os, mask, (uint32_t*)nullptr, 0u);
+                return RT_OK;
+            }
             if (vn == 71) {  // the shipped kernel without a plan of expensive blocks
                 const uint32_t* no_mask = nullptr;
                 hipLaunchKernelGGL((k_trace_primary_lean<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os, no_mask, (uint32_t*)nullptr, 0u);

@@ -685,6 +685,11 @@ __device__ inline RayDir late_shadow_dir(uint32_t frame_byte_offset) {
 }
 static_assert(sizeof(RayDir) == 60 && offsetof(RayDir, sx) == 36 && offsetof(RayDir, dix) == 48, "late_shadow_dir reads RayDir word by word");
 
+#ifdef RT_EXPERIMENTS
+__device__ unsigned long long g_wave_t[2 * 65536];  // development builds: s_memrealtime (100 MHz) at wave start / end,
+__device__ uint32_t g_wave_chain[65536];            // and the cost a block reported (bits 30-31: its class)
+#endif
+
 // LATE: the kernel's arguments are exactly PrimaryArgs' members in that order, and what the epilogue needs of them is
 // read again there instead of being kept in scalar registers through both traversals.
 // FRAMES (with LATE): the kernel's arguments are PrimaryFramesArgs', blockIdx.y picks the frame.
@@ -692,6 +697,9 @@ template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX, bool WIDE, bo
 __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f, const ShardMap& m, uint2* __restrict__ out_p,
                                            uint2* __restrict__ out_s, unsigned long long* stats, const uint32_t* cull_mask = nullptr) {
     static_assert(!FRAMES || LATE, "the frames kernel reads its arguments late");
+#ifdef RT_EXPERIMENTS
+    const unsigned long long t_wave_start = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr uint32_t A_M = FRAMES ? offsetof(PrimaryFramesArgs, m) : offsetof(PrimaryArgs, m);
     constexpr uint32_t A_OUT_P = FRAMES ? offsetof(PrimaryFramesArgs, out_p) : offsetof(PrimaryArgs, out_p);
     constexpr uint32_t A_OUT_S = FRAMES ? offsetof(PrimaryFramesArgs, out_s) : offsetof(PrimaryArgs, out_s);
@@ -772,6 +780,15 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
         }
     }
     if (STATS) flush_stats(stats, n_rays, n_ph, n_sr, n_sh, ctr);
+#ifdef RT_EXPERIMENTS
+    if (LATE && !FRAMES && lane == 0) {  // development builds: when this wave ran (tools/wave_timeline.py)
+        const uint32_t gw = blockIdx.x * 4 + w4;
+        if (gw < 65536) {
+            g_wave_t[2 * gw] = t_wave_start;
+            g_wave_t[2 * gw + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 template <bool WGSL, bool SHADOW, int STATS, bool BOXES, bool TEX = false, bool WIDE = false>
@@ -898,10 +915,6 @@ __device__ inline void steer_plan(const BlockPlan& p, const PlanReader& plan) { 
     BlockPlan::word(p.next, 8) = plan_threshold(p, plan);  // what this launch makes the next list with
 }
 
-#ifdef RT_EXPERIMENTS
-__device__ unsigned long long g_wave_t[2 * 65536];  // development builds: s_memrealtime (100 MHz) at wave start / end,
-__device__ uint32_t g_wave_chain[65536];            // and the cost a block reported (bits 30-31: its class)
-#endif
 
 // k_trace_primary for triangle-only scenes without counters (the common case), with the plan above. The grid is
 // cap_heavy workgroups for the heavy list, cap_early / 4 for the early list (those beyond a list's length exit at

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Development tool: when each wave of one primary+shadow launch started and ended. RT_VARIANT=30: the instrumented
+"""Development tool: when each wave of one primary+shadow launch started and ended. RT_VARIANT=71 / 72: the shipped
+kernel without / with the frame's block mask (stamped in development builds). RT_VARIANT=30: the instrumented
 plain kernel, one wave per 8x8 pixel block (build with `make -C ray-tracer_amd/csrc exp VARS="0 30"`); RT_VARIANT=99: the
 shipped kernel with its plan of expensive blocks (RT_HEAVY = the threshold), which stamps itself in development builds.
 Prints the launch's span, the distribution of run times, how many waves were resident over time, and what ended last."""

@@ -466,17 +466,17 @@ def main():
     if not multi:
         base_ms = same_route_single_gpu(core, sharding, cam, dev, max(64, args.steps))
     hbm_copy = None
-    if not multi:  # what this GPU's HBM delivers on a plain copy (2 GiB read + 2 GiB written), beside the 8 TB/s spec
-        a = torch.empty(1 << 29, dtype=torch.float32, device=dev)
+    if not multi:  # what this GPU's HBM delivers on the library's plain copy kernel (2 GiB read + 2 GiB written per pass)
+        a = torch.zeros(1 << 29, dtype=torch.float32, device=dev)
         b = torch.empty_like(a)
-        b.copy_(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            b.copy_(a)
-        e1.record()
         torch.cuda.synchronize()
-        hbm_copy = 2 * a.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        core.set_stream(None)
+        nbytes = a.numel() * 4
+        core.probe_copy(a.data_ptr(), b.data_ptr(), nbytes)
+        core.timer_begin()
+        for _ in range(5):
+            core.probe_copy(a.data_ptr(), b.data_ptr(), nbytes)
+        hbm_copy = 2 * nbytes * 5 / (core.timer_end() * 1e-3) / 1e9
         del a, b
     if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -478,6 +478,12 @@ int rt_intersect_tri_pairs_watertight(rt_ctx* ctx, const float* origins, const f
 int rt_timer_begin(rt_ctx* ctx);
 int rt_timer_end(rt_ctx* ctx, float* elapsed_ms); /* synchronises on the end event */
 
+/* Measurement aid without a counterpart in the reference: queues a plain copy of `bytes` bytes of device memory (16
+ * bytes per lane, read once, written once) on the context's stream. Timed between rt_timer_begin / rt_timer_end over
+ * buffers far larger than the caches it gives what this GPU's HBM delivers, the figure to hold a kernel's measured
+ * traffic against beside the 8 TB/s of the data sheet. Size and both addresses must be multiples of 16. */
+int rt_probe_copy(rt_ctx* ctx, const void* src, void* dst, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,6 +166,7 @@ PROTOTYPES = {
     "rt_intersect_tri_pairs_watertight": (_I, [_VP, _VP, _VP, _U32, _VP, _U32, _VP]),
     "rt_timer_begin": (_I, [_VP]),
     "rt_timer_end": (_I, [_VP, C.POINTER(C.c_float)]),
+    "rt_probe_copy": (_I, [_VP, _VP, _VP, C.c_size_t]),
 }
 
 _lib = None

@@ -1949,6 +1949,30 @@ extern "C" int rt_timer_begin(rt_ctx* c) {
     return RT_OK;
 }
 
+// What this GPU's memory delivers on the plainest access there is: 16 bytes per lane, read once, written once, past the
+// caches. One element per lane and a workgroup per 4 KB is the fastest shape measured on the MI355X (6.5 TB/s over
+// 2 GiB; a grid sized to the chip whose lanes loop with 2-8 loads in flight: 4.6-5.6 TB/s; hipMemcpyAsync: 4.9).
+typedef uint32_t probe_vec __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_probe_copy(const probe_vec* __restrict__ src, probe_vec* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+extern "C" int rt_probe_copy(rt_ctx* c, const void* src, void* dst, size_t bytes) {
+    if (int r = use(c)) return r;
+    if (!src || !dst) return fail(c, RT_ERR_INVALID, "rt_probe_copy: NULL buffer");
+    if ((bytes & 15u) || ((uintptr_t)src & 15u) || ((uintptr_t)dst & 15u))
+        return fail(c, RT_ERR_INVALID, "rt_probe_copy: size and addresses must be multiples of 16 bytes");
+    if (!is_device_ptr(src) || !is_device_ptr(dst)) return fail(c, RT_ERR_INVALID, "rt_probe_copy: device memory only");
+    if (bytes == 0) return RT_OK;
+    const size_t n = bytes / 16, wgs = (n + 255) / 256;
+    if (wgs > 0x7FFFFFFFull) return fail(c, RT_ERR_LIMIT, "rt_probe_copy: at most 8 TiB in one call");
+    hipLaunchKernelGGL(k_probe_copy, dim3((uint32_t)wgs), dim3(256), 0, c->stream, static_cast<const probe_vec*>(src),
+                       static_cast<probe_vec*>(dst), n);
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
 extern "C" int rt_timer_end(rt_ctx* c, float* elapsed_ms) {
     if (int r = use(c)) return r;
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));

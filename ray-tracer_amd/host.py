@@ -162,6 +162,10 @@ class TraceCore:
         self._ck(self._L.rt_timer_end(self._h, C.byref(ms)))
         return ms.value
 
+    def probe_copy(self, src_ptr, dst_ptr, nbytes):
+        """Queue a plain device-to-device copy on the context's stream (a bandwidth probe; time it with the timer)."""
+        self._ck(self._L.rt_probe_copy(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), nbytes))
+
     # ---- scene / grid
     def set_scene(self, boxes=None, tris=None):
         boxes = np.ascontiguousarray(boxes if boxes is not None else np.zeros(0, BOX_DTYPE), BOX_DTYPE)

@@ -774,3 +774,25 @@ def test_errors_are_reported(core, rt, ob):
         core.set_grid_csr(meta, np.array([5, 3], np.uint32), np.zeros(5, np.uint32))  # decreasing offsets
     with pytest.raises(rt.RtError):
         core.update_vertices(np.zeros((7, 9), np.float32))  # more triangles than the scene has
+
+
+@pytest.mark.gpu
+def test_probe_copy_copies_and_rejects_what_it_cannot(rt, core):
+    """rt_probe_copy (the bandwidth probe bench.py times) is a byte-exact copy for every size in 16-byte units and an
+    error for anything else."""
+    import torch
+    src = torch.randint(-2**31, 2**31 - 1, (1 << 25,), dtype=torch.int32, device="cuda")
+    dst = torch.empty_like(src)
+    for units in (0, 1, 255, 256, 257, 5767245, src.numel() // 4):  # 16-byte units: part workgroups, whole ones, all
+        words = 4 * units
+        assert words <= src.numel() and words <= dst.numel()  # the kernel trusts the size it is given
+        dst.fill_(7)
+        torch.cuda.synchronize()
+        core.probe_copy(src.data_ptr(), dst.data_ptr(), 4 * words)
+        core.sync()
+        assert torch.equal(dst[:words], src[:words]) and bool((dst[words:] == 7).all()), units
+    host = np.zeros(64, np.int32)
+    for args in ((src.data_ptr(), dst.data_ptr(), 24), (src.data_ptr() + 4, dst.data_ptr(), 32),
+                 (host.ctypes.data, dst.data_ptr(), 64), (0, dst.data_ptr(), 64)):
+        with pytest.raises(rt.RtError):
+            core.probe_copy(*args)

@@ -13,7 +13,7 @@ pub const RT_MISS: u32 = 0xFFFF_FFFF;
 pub struct RtParams {
     pub finest_cell_size: f32, pub max_objects_per_cell: u32, pub max_dda_steps: u32, pub wgsl_compat: u32,
     pub lod_cull: u32, pub moving_box_count: u32, pub fov: f32, pub light_direction: [f32; 3],
-    pub shadow_offset: f32, pub collect_stats: u32, pub skip_duplicate_triangles: u32, pub heavy_block_threshold: u32, pub cull_empty_blocks: u32,
+    pub shadow_offset: f32, pub collect_stats: u32, pub skip_duplicate_triangles: u32, pub heavy_block_threshold: u32, pub cull_empty_blocks: u32, pub repack_candidates: u32,
 }
 
 #[repr(C)]

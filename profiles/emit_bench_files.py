@@ -28,6 +28,7 @@ else:
     rs = bench["roofline_streaming"]
     rec = {"source": source, "triangles": int(re.match(r"(\d+) distinct", rs["workload"]).group(1)),
            "cell_size": float(re.search(r"grid cell ([0-9.]+)", rs["workload"]).group(1)),
+           "repack_candidates": int(rs.get("repack_candidates", 0)), "kernel": d["kernel"],
            "bytes_per_launch": derived["hbm_bytes_per_launch"], "read_bytes_per_launch": derived["hbm_read_bytes_per_launch"],
            "write_bytes_per_launch": derived["hbm_write_bytes_per_launch"]}
     for k in ("l2_hit_rate", "lanes_active_per_valu_instruction", "ta_busy_frac", "valu_issue_frac"):

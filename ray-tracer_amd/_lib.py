@@ -55,7 +55,8 @@ class RtParams(C.Structure):
     _fields_ = [("finest_cell_size", C.c_float), ("max_objects_per_cell", C.c_uint32), ("max_dda_steps", C.c_uint32),
                 ("wgsl_compat", C.c_uint32), ("lod_cull", C.c_uint32), ("moving_box_count", C.c_uint32),
                 ("fov", C.c_float), ("light_direction", C.c_float * 3), ("shadow_offset", C.c_float),
-                ("collect_stats", C.c_uint32), ("skip_duplicate_triangles", C.c_uint32), ("heavy_block_threshold", C.c_uint32), ("cull_empty_blocks", C.c_uint32)]
+                ("collect_stats", C.c_uint32), ("skip_duplicate_triangles", C.c_uint32), ("heavy_block_threshold", C.c_uint32), ("cull_empty_blocks", C.c_uint32),
+                ("repack_candidates", C.c_uint32)]
 
 
 class RtShard(C.Structure):

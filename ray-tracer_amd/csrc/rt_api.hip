@@ -768,7 +768,10 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
         rt_plan* plan = nullptr;
         if (may_alloc && c->params.heavy_block_threshold && (uint64_t)grid.x * 4 + PLAN_LEAD_WGS < 0x7FFFFFFFull)
             if (int r = plan_for(c, m, f, grid.x * 4, SHADOW, &plan)) return r;
-        if (plan) {
+        if (!plan && c->params.repack_candidates) {
+            // rays of a wave in different cells: (ray, candidate) pairs dealt out again to the lanes (trace_ray_repack)
+            hipLaunchKernelGGL((k_trace_primary_repack<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os);
+        } else if (plan) {
             const BlockPlan bp = make_block_plan(plan, c->params.heavy_block_threshold);
             hipLaunchKernelGGL((k_trace_primary_planned<WGSL, SHADOW>), dim3(grid.x + PLAN_LEAD_WGS), dim3(256), 0, c->stream, s, f, m, bp, op, os);
             plan->cur = (plan->cur + 1) % 3;
@@ -912,6 +915,7 @@ extern "C" void rt_default_params(rt_params* p) {
     p->skip_duplicate_triangles = 1;
     p->heavy_block_threshold = 0;
     p->cull_empty_blocks = 1;
+    p->repack_candidates = 0;
 }
 
 extern "C" const char* rt_create_error(void) { return g_create_error.c_str(); }
@@ -1389,7 +1393,7 @@ extern "C" int rt_trace_primary_frames(rt_ctx* c, const CameraUniform* cams, uin
     const DevScene s = make_scene(c);
     const bool host_out = !is_device_ptr(out_primary) || (out_shadow && !is_device_ptr(out_shadow));
     const bool grouped = !c->params.collect_stats && c->grid_nb == 0 && c->tex_mode != 2 && !wide_grid(s) &&
-                         !c->params.heavy_block_threshold && !host_out && n_frames > 1;
+                         !c->params.heavy_block_threshold && !c->params.repack_candidates && !host_out && n_frames > 1;
     if (!grouped) {
         for (uint32_t j = 0; j < n_frames; ++j)
             if (int r = trace_primary<false>(c, cams + j, width, height, shard, out_primary + j * stride,

@@ -821,6 +821,252 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_tr
     trace_primary_block<WGSL, SHADOW, 0, false, false, false, true, true>(s, fs.f[blockIdx.y], m, out_p, out_s, nullptr);
 }
 
+// trace_ray for waves whose rays sit in DIFFERENT cells with lists of different lengths (rt_params.repack_candidates):
+// (ray, candidate) pairs are dealt out again to the lanes of the wave at DDA steps where that keeps more lanes busy. All 64
+// lanes run one wave-uniform loop, whether their own ray is still alive or not. Per step: a prefix sum of the alive
+// lanes' list lengths numbers the wave's pairs 0 .. total-1; pair p goes to lane p % 64 in round p / 64, which finds its
+// ray (a binary search over the prefix sums in LDS), fetches that ray and its re-test mask from LDS, the candidate's
+// record from memory, and runs the ordinary test. Results meet in one 64-bit LDS word per ray through an unsigned
+// minimum: closest hit (t bits, 1 + list position), which starts as (closest so far, 0) - a positive float's bits order
+// as the float does, so the minimum is the smallest t, among equal t the earliest position, and a candidate that only
+// equals the closest so far loses, which is what scanning the list in order with a strict '<' yields; any-hit
+// (1 + list position, t bits): the earliest accepted position. Rays that start outside the grid take the ordinary
+// function afterwards. Triangle-only scenes, no counters, no texture-decided hits, reference records within 4 GiB.
+struct RepackLds {
+    unsigned long long key[64];
+    uint32_t excl[64];
+    float4 o_arrival[64];  // the ray's origin and its re-test mask
+    float4 d_first[64];    // its direction and the first record of its current cell's list
+};
+
+// inclusive prefix sum over the wave's 64 lanes: four shifts inside each row of 16, then the row totals across
+__device__ inline uint32_t wave_prefix_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// the largest x of the wave's 64 lanes (valid in lane 63; read it with readlane)
+__device__ inline uint32_t wave_running_max(uint32_t x) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
+    return x;
+}
+
+// MODE 0: pairs are dealt out at every step. MODE 1 / 2: only at steps where that is estimated to cost less than every
+// lane scanning its own list (rounds of 64 pairs against the longest list of the wave, weighed by what a round and a
+// trip of the plain loop cost in instructions; 2 is more eager), the plain scan otherwise.
+template <bool WGSL, bool ANY, int MODE = 1>
+__device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& rd, bool active, HitRec& out, RepackLds& L) {
+    const uint32_t lane = threadIdx.x & 63;
+    float closest = 1e10f;
+    uint32_t best_ref = MISS;
+    const V3 d = rd.d, inv = rd.inv;
+    const v4i refs_d = make_rsrc(s.refs, 48, s.n_refs + 1);
+    const v4i cells_d = make_rsrc(s.cells, 8, s.n_bordered);
+    const V3 bmin = v3(s.bmin[0], s.bmin[1], s.bmin[2]), bmax = v3(s.bmax[0], s.bmax[1], s.bmax[2]);
+    const float cs = s.cell_size;
+    bool alive = active;
+    V3 pos = o;
+    float t_off = 0.0f;
+    if (pos.x < bmin.x || pos.x > bmax.x || pos.y < bmin.y || pos.y > bmax.y || pos.z < bmin.z || pos.z > bmax.z) {
+        const float t_entry = slab(o, inv, bmin, bmax);
+        if (t_entry < 0.0f) alive = false;
+        t_off = t_entry + 0.001f;
+        pos = o + d * t_off;
+        const float e = 0.0001f;
+        pos = vmin(vmax(pos, bmin + v3(e, e, e)), bmax - v3(e, e, e));
+    }
+    uint32_t cx, cy, cz;
+    {
+        const V3 rel = pos - bmin;
+        const float ics = s.inv_cell_size;
+        cx = f2u_sat(fmaxf(0.0f, floorf(rel.x * ics)));
+        cy = f2u_sat(fmaxf(0.0f, floorf(rel.y * ics)));
+        cz = f2u_sat(fmaxf(0.0f, floorf(rel.z * ics)));
+    }
+    const bool literal = alive && (cx >= s.gx || cy >= s.gy || cz >= s.gz);  // start cell outside the grid
+    if (literal) alive = false;
+    const uint32_t sx = rd.sx, sy = rd.sy, sz = rd.sz, dix = rd.dix, diy = rd.diy, diz = rd.diz;
+    const V3 cell_world = bmin + v3((float)cx, (float)cy, (float)cz) * cs;
+    const V3 next_b = cell_world + v3(sx == 1u ? cs : 0.0f, sy == 1u ? cs : 0.0f, sz == 1u ? cs : 0.0f);
+    const V3 t_delta = rd.t_delta;
+    V3 t_max = v3(t_off, t_off, t_off) + (next_b - pos) * inv;
+    {
+        const float fl = t_off + 0.00001f;
+        t_max = vmax(t_max, v3(fl, fl, fl));
+    }
+    const uint32_t mx = sx == 1u ? 1u : 2u, my = sy == 1u ? 4u : 8u, mz = sz == 1u ? 16u : 32u;
+    uint32_t arrival = 0;
+    uint32_t idx = alive ? (cx + 1u) + (cy + 1u) * s.px + (cz + 1u) * s.pxy : 0u;  // 0: a border cell, a sentinel
+    uint2 cell = buf_load8(cells_d, idx);
+    uint32_t left = s.max_steps;
+    alive = alive && left != 0 && cell.y != CELL_SENTINEL;
+    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {  // the same in every lane
+        // the step this trip ends with depends on t_max only: the next cell's record is asked for before the pairs
+        const bool ax = t_max.x < t_max.y && t_max.x < t_max.z;
+        const bool ay = !ax && t_max.y < t_max.z;
+        const bool az = !ax && !ay;
+        const float t_exit = fminf(fminf(t_max.x, t_max.y), t_max.z);
+        const uint32_t idx_next = alive ? idx + (ax ? dix : (ay ? diy : diz)) : 0u;
+        const uint2 cell_next = buf_load8(cells_d, idx_next);
+        const uint32_t n = alive ? cell.y : 0u;
+        const uint32_t incl = wave_prefix_sum(n);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        bool deal = total != 0;
+        if (MODE != 0 && deal) {
+            const uint32_t longest = (uint32_t)__builtin_amdgcn_readlane((int)wave_running_max(n), 63);
+            const uint32_t rounds = (total + 63u) >> 6;
+            deal = MODE == 1 ? rounds * 130u + 50u < longest * 55u : rounds * 100u < longest * 55u;
+        }
+        if (!deal) {
+            if (n != 0) {  // this lane's own list, two records per trip, each loaded while the other is tested
+                auto test = [&](const float4& c0, const float4& c1, const float4& c2, uint32_t r) -> bool {
+                    if (__float_as_uint(c1.w) & arrival) return false;
+                    const float t = moller_trumbore_pk<WGSL>(make_ray_pk(o, d), c0, c1, c2);
+                    if (t > 0.0f && t < closest && __float_as_uint(c0.w) < REF_INVISIBLE) {
+                        closest = t;
+                        best_ref = r;
+                        return ANY;
+                    }
+                    return false;
+                };
+                uint32_t r = cell.x;
+                const uint32_t r_end = r + n;
+                float4 a0 = buf_load16<0>(refs_d, r), a1 = buf_load16<16>(refs_d, r), a2 = buf_load16<32>(refs_d, r);
+                for (;;) {
+                    const float4 b0 = buf_load16<0>(refs_d, r + 1), b1 = buf_load16<16>(refs_d, r + 1), b2 = buf_load16<32>(refs_d, r + 1);
+                    if (test(a0, a1, a2, r)) break;
+                    if (++r == r_end) break;
+                    a0 = buf_load16<0>(refs_d, r + 1), a1 = buf_load16<16>(refs_d, r + 1), a2 = buf_load16<32>(refs_d, r + 1);
+                    if (test(b0, b1, b2, r)) break;
+                    if (++r == r_end) break;
+                }
+            }
+        } else {
+            L.excl[lane] = incl - n;
+            L.o_arrival[lane] = make_float4(o.x, o.y, o.z, __uint_as_float(arrival));
+            L.d_first[lane] = make_float4(d.x, d.y, d.z, __uint_as_float(cell.x));
+            L.key[lane] = ANY ? ~0ull : ((unsigned long long)__float_as_uint(closest) << 32);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t p0 = 0; p0 < total; p0 += 64) {
+                const uint32_t p = p0 + lane;
+                if (p < total) {
+                    uint32_t j = 0;  // the last lane whose first pair is not after p: the ray pair p belongs to
+#pragma unroll
+                    for (uint32_t step = 32; step != 0; step >>= 1)
+                        if (L.excl[j + step] <= p) j += step;
+                    const uint32_t k = p - L.excl[j];
+                    const float4 df = L.d_first[j];
+                    const uint32_t rec = __float_as_uint(df.w) + k;
+                    const float4 c0 = buf_load16<0>(refs_d, rec), c1 = buf_load16<16>(refs_d, rec), c2 = buf_load16<32>(refs_d, rec);
+                    const float4 oa = L.o_arrival[j];
+                    if (!(__float_as_uint(c1.w) & __float_as_uint(oa.w))) {
+                        const RayPk rp = make_ray_pk(v3(oa.x, oa.y, oa.z), v3(df.x, df.y, df.z));
+                        const float t = moller_trumbore_pk<WGSL>(rp, c0, c1, c2);
+                        if (t > 0.0f && t < 1e10f && __float_as_uint(c0.w) < REF_INVISIBLE) {
+                            const unsigned long long key = ANY ? ((unsigned long long)(k + 1u) << 32) | __float_as_uint(t)
+                                                               : ((unsigned long long)__float_as_uint(t) << 32) | (k + 1u);
+                            atomicMin(&L.key[j], key);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long key = L.key[lane];
+            if (alive && n != 0) {
+                if (ANY) {
+                    if (key != ~0ull) {
+                        best_ref = cell.x + (uint32_t)(key >> 32) - 1u;
+                        closest = __uint_as_float((uint32_t)key);
+                    }
+                } else if ((uint32_t)key != 0u) {
+                    closest = __uint_as_float((uint32_t)(key >> 32));
+                    best_ref = cell.x + (uint32_t)key - 1u;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // the next step overwrites the words only after every lane has read its own
+        }
+        if (alive) {
+            const bool hit = best_ref != MISS;
+            --left;
+            const bool stop = (ANY & hit) | (hit & (closest < t_exit)) | (left == 0);
+            idx = idx_next;
+            arrival = ax ? mx : (ay ? my : mz);
+            t_max.x += ax ? t_delta.x : 0.0f;
+            t_max.y += ay ? t_delta.y : 0.0f;
+            t_max.z += az ? t_delta.z : 0.0f;
+            cell = cell_next;
+            alive = !stop && cell.y != CELL_SENTINEL;
+        }
+    }
+    bool got = best_ref != MISS;
+    out = HitRec{closest, MISS, best_ref};
+    if (got) out.id = __float_as_uint(buf_load16<0>(refs_d, best_ref).w);  // the hit record's id, read once at the end
+    if (literal) {
+        Counters ctr{};
+        got = trace_ray<WGSL, ANY, 0, false, false, false, 2>(s, o, rd, out, ctr);  // the form without an LDS buffer
+    }
+    return active && got;
+}
+
+
+// k_trace_primary with trace_ray_repack as the traversal: every lane of a wave enters both traversals, with or without
+// a ray of its own.
+template <bool WGSL, bool SHADOW>
+__global__ __launch_bounds__(256, 6) void k_trace_primary_repack(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
+                                                              uint2* __restrict__ out_s) {
+    __shared__ RepackLds repack[4];
+    const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
+    const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;  // 16x16 blocks per tile
+    const uint32_t blk_per_tile = blk_x * blk_y;
+    const uint32_t lt = blockIdx.x / blk_per_tile, blk = blockIdx.x % blk_per_tile;
+    if (lt >= m.n_local) return;  // whole workgroup
+    const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
+    const uint32_t lx = sub_x * 8 + (lane & 7), ly = sub_y * 8 + (lane >> 3);
+    const uint32_t tile = shard_tile(m, lt);
+    const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
+    const bool in_tile = lx < m.tile_w && ly < m.tile_h;
+    const bool live = in_tile && px < f.width && py < f.height;
+    RepackLds& L = repack[w4 & 3];
+    uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
+    const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+    const V3 d = primary_dir(f, live ? px : 0u, live ? py : 0u);
+    const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
+    HitRec h;
+    const bool hit = trace_ray_repack<WGSL, false>(s, o, rd, live, h, L);
+    if (hit) ph = make_uint2(h.id, __float_as_uint(h.t));
+    if (SHADOW) {
+        V3 so = o;
+        if (hit) {
+            const V3 pos = o + d * h.t;
+            V3 n = hit_normal(s, h, pos);
+            if (dot(n, d) > 0.0f) n = neg(n);
+            so = pos + n * f.shadow_offset;
+        }
+        HitRec oh;
+        if (trace_ray_repack<WGSL, true>(s, so, f.shadow, hit, oh, L)) sh = make_uint2(oh.id, __float_as_uint(oh.t));
+    }
+    if (in_tile) {
+        const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
+        out_p[oi] = ph;
+        if (SHADOW) out_s[oi] = sh;
+    }
+}
+
 // Pixel blocks that are expensive: a plan made by one launch for the next one of the same frame shape.
 //
 // A frame's duration is not its work: the chip is full for the first two thirds of a launch, then drains for as long

@@ -24,6 +24,7 @@ __device__ inline bool trace_ray_x(const DevScene& s, V3 o, const RayDir& rd, Hi
 }
 
 
+// Bodies 6 / 7 / 8: trace_ray_repack (rt_trace.hpp) with MODE 0 / 1 / 2.
 template <int VARIANT>
 struct VarCfg {
     static constexpr int body = VARIANT % 10;
@@ -146,7 +147,26 @@ __device__ inline void trace_block(const DevScene& s, const DevFrame& f, const S
         if constexpr (BODY == 0) return trace_ray<false, ANY, 0, false>(s, o, rd, h, ctr);
         else return trace_ray_x<BODY, ANY>(s, o, rd, h);
     };
-    if (live) {
+    if constexpr (BODY >= 6 && BODY <= 8) {  // every lane of the wave takes part, with or without a ray of its own
+        constexpr int MODE = BODY - 6;
+        __shared__ RepackLds repack[4];
+        RepackLds& L = repack[(threadIdx.x >> 6) & 3];
+        const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+        const V3 d = primary_dir(f, live ? px : 0u, live ? py : 0u);
+        HitRec h;
+        const RayDir rd = make_ray_dir<false>(d, s.cell_size, s.px, s.pxy);
+        const bool hit = trace_ray_repack<false, false, MODE>(s, o, rd, live, h, L);
+        V3 so = o;
+        if (hit) {
+            ph = make_uint2(h.id, __float_as_uint(h.t));
+            const V3 pos = o + d * h.t;
+            V3 n = hit_normal(s, h, pos);
+            if (dot(n, d) > 0.0f) n = neg(n);
+            so = pos + n * f.shadow_offset;
+        }
+        HitRec oh;
+        if (trace_ray_repack<false, true, MODE>(s, so, f.shadow, hit, oh, L)) sh = make_uint2(oh.id, __float_as_uint(oh.t));
+    } else if (live) {
         const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         const V3 d = primary_dir(f, px, py);
         HitRec h;

@@ -46,7 +46,7 @@ def test_wire_struct_sizes(rt):
     # sizes asserted in include/rt_types.h (reference src/types.rs, src/grid.rs)
     assert C.sizeof(rt.CameraUniform) == 80 and C.sizeof(rt.GridMetadata) == 96 and C.sizeof(rt.RayDebugInfo) == 80
     assert rt.BOX_DTYPE.itemsize == 96 and rt.TRIANGLE_DTYPE.itemsize == 80 and rt.HIT_DTYPE.itemsize == 8
-    assert C.sizeof(rt.RtStats) == 88 and C.sizeof(rt.RtShard) == 24 and C.sizeof(rt.RtParams) == 60
+    assert C.sizeof(rt.RtStats) == 88 and C.sizeof(rt.RtShard) == 24 and C.sizeof(rt.RtParams) == 64
 
 
 def test_oracle_binding_shares_the_header_structs(rt, ob):

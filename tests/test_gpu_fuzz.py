@@ -65,7 +65,8 @@ def test_random_scenes(rt, ob):
         # expensive-block plan: off, the default, or so low that every block with a candidate is traced four lanes per ray
         heavy = int(rng.choice([0, 64, 1, 3]))
         # block mask: every frame of a triangle-only scene without a plan (2), or as the default decides (1: lone frames get none)
-        core = rt.TraceCore(0, rt.default_params(heavy_block_threshold=heavy, cull_empty_blocks=2 - trial % 2, **kw))
+        core = rt.TraceCore(0, rt.default_params(heavy_block_threshold=heavy, cull_empty_blocks=2 - trial % 2,
+                                                    repack_candidates=int(trial % 3 == 1), **kw))
         core.set_scene(boxes, tris)
         core.set_materials(mats)
         try:

@@ -864,7 +864,8 @@ __device__ inline uint32_t wave_running_max(uint32_t x) {
 
 // MODE 0: pairs are dealt out at every step. MODE 1 / 2: only at steps where that is estimated to cost less than every
 // lane scanning its own list (rounds of 64 pairs against the longest list of the wave, weighed by what a round and a
-// trip of the plain loop cost in instructions; 2 is more eager), the plain scan otherwise.
+// trip of the plain loop cost in instructions; 2 deals less readily: measured, slower, as is a more eager rule), the
+// plain scan otherwise.
 template <bool WGSL, bool ANY, int MODE = 1>
 __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& rd, bool active, HitRec& out, RepackLds& L) {
     const uint32_t lane = threadIdx.x & 63;
@@ -926,7 +927,7 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
         if (MODE != 0 && deal) {
             const uint32_t longest = (uint32_t)__builtin_amdgcn_readlane((int)wave_running_max(n), 63);
             const uint32_t rounds = (total + 63u) >> 6;
-            deal = MODE == 1 ? rounds * 130u + 50u < longest * 55u : rounds * 100u < longest * 55u;
+            deal = MODE == 1 ? rounds * 130u + 50u < longest * 55u : rounds * 180u + 100u < longest * 55u;
         }
         if (!deal) {
             if (n != 0) {  // this lane's own list, two records per trip, each loaded while the other is tested

@@ -85,7 +85,7 @@ extern "C" {
 /// `rt_render_opts` of include/rt_mi355.h.
 #[repr(C)]
 #[derive(Copy, Clone, Default)]
-pub struct RtRenderOpts { pub max_bounces: u32, pub shadows: u32, pub debug_enabled: u32, pub debug_pixel: [u32; 2], pub pixel_format: u32, pub frame_stride: u32, pub _pad: u32 }
+pub struct RtRenderOpts { pub max_bounces: u32, pub shadows: u32, pub debug_enabled: u32, pub debug_pixel: [u32; 2], pub pixel_format: u32, pub frame_stride: u32, pub plain_bounces: u32 }
 
 /// Owns one context. `Send` but not `Sync`: the C side is not re-entrant (one in-order stream).
 pub struct TraceCore { ctx: *mut RtCtx }

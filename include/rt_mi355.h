@@ -384,7 +384,12 @@ typedef struct rt_render_opts {
     uint32_t frame_stride;    /* rt_render_frames: pixels from one frame's output to the next; 0 = packed (the pixels
                                  one frame writes). Ranks whose shards differ in size use a common stride, so that the
                                  gathered blocks have one layout */
-    uint32_t _pad;
+    uint32_t plain_bounces;   /* 0 (default): in pictures with reflection bounces of triangle-only scenes the scattered
+                                 rays of a wave share their candidate lists from the first reflection on (k_render_deal;
+                                 with texture-decided alpha only from six bounces up, where it pays) - the same picture
+                                 byte for byte, the 8-bounce picture of the bundled static model 179 -> 167 us, without
+                                 its alpha textures 166 -> 148. 1: every ray scans its own lists (k_render). No reference
+                                 counterpart */
 } rt_render_opts;
 #define RT_PIXEL_RGBA8 0u
 #define RT_PIXEL_RGB8 1u

@@ -98,7 +98,7 @@ class RtTexture(C.Structure):
 
 class RtRenderOpts(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("shadows", C.c_uint32), ("debug_enabled", C.c_uint32),
-                ("debug_pixel", C.c_uint32 * 2), ("pixel_format", C.c_uint32), ("frame_stride", C.c_uint32), ("_pad", C.c_uint32)]
+                ("debug_pixel", C.c_uint32 * 2), ("pixel_format", C.c_uint32), ("frame_stride", C.c_uint32), ("plain_bounces", C.c_uint32)]
 
 
 class RayDebugInfo(C.Structure):

@@ -866,7 +866,7 @@ __device__ inline uint32_t wave_running_max(uint32_t x) {
 // lane scanning its own list (rounds of 64 pairs against the longest list of the wave, weighed by what a round and a
 // trip of the plain loop cost in instructions; 2 deals less readily: measured, slower, as is a more eager rule), the
 // plain scan otherwise.
-template <bool WGSL, bool ANY, int MODE = 1>
+template <bool WGSL, bool ANY, int MODE = 1, bool TEX = false>
 __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& rd, bool active, HitRec& out, RepackLds& L) {
     const uint32_t lane = threadIdx.x & 63;
     float closest = 1e10f;
@@ -935,6 +935,13 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
                     if (__float_as_uint(c1.w) & arrival) return false;
                     const float t = moller_trumbore_pk<WGSL>(make_ray_pk(o, d), c0, c1, c2);
                     if (t > 0.0f && t < closest && __float_as_uint(c0.w) < REF_INVISIBLE) {
+                        if (TEX && __float_as_uint(c2.w) != 0u) {  // the hit's alpha is a texture's: sampled per hit
+                            const uint32_t mat = __float_as_uint(c2.w) - 1u;
+                            float bu, bv;
+                            hit_barycentrics(o, d, v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z), v3(c2.x, c2.y, c2.z), bu, bv);
+                            const float4 bc = base_color(s.tex, mat, hit_uv(s.tex, __float_as_uint(c0.w) - s.nb, bu, bv));
+                            if (alpha_discards(s.tex, mat, bc.w)) return false;
+                        }
                         closest = t;
                         best_ref = r;
                         return ANY;
@@ -976,7 +983,24 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
                     if (!(__float_as_uint(c1.w) & __float_as_uint(oa.w))) {
                         const RayPk rp = make_ray_pk(v3(oa.x, oa.y, oa.z), v3(df.x, df.y, df.z));
                         const float t = moller_trumbore_pk<WGSL>(rp, c0, c1, c2);
-                        if (t > 0.0f && t < 1e10f && __float_as_uint(c0.w) < REF_INVISIBLE) {
+                        bool accepted = t > 0.0f && t < 1e10f && __float_as_uint(c0.w) < REF_INVISIBLE;
+                        if (TEX && accepted && __float_as_uint(c2.w) != 0u) {
+                            // The alpha rule is a function of the hit alone, so a rejected candidate is rejected whatever
+                            // the scan has seen before it: the minimum over the candidates that pass it is the in-order
+                            // scan's answer. Candidates that cannot win any more are not sampled.
+                            const unsigned long long now = L.key[j];
+                            const bool can_win = ANY ? (uint32_t)(now >> 32) > k + 1u : (uint32_t)(now >> 32) >= __float_as_uint(t);
+                            accepted = can_win;
+                            if (can_win) {
+                                const uint32_t mat = __float_as_uint(c2.w) - 1u;
+                                float bu, bv;
+                                hit_barycentrics(v3(oa.x, oa.y, oa.z), v3(df.x, df.y, df.z), v3(c0.x, c0.y, c0.z), v3(c1.x, c1.y, c1.z),
+                                                 v3(c2.x, c2.y, c2.z), bu, bv);
+                                const float4 bc = base_color(s.tex, mat, hit_uv(s.tex, __float_as_uint(c0.w) - s.nb, bu, bv));
+                                accepted = !alpha_discards(s.tex, mat, bc.w);
+                            }
+                        }
+                        if (accepted) {
                             const unsigned long long key = ANY ? ((unsigned long long)(k + 1u) << 32) | __float_as_uint(t)
                                                                : ((unsigned long long)__float_as_uint(t) << 32) | (k + 1u);
                             atomicMin(&L.key[j], key);
@@ -1019,7 +1043,7 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
     if (got) out.id = __float_as_uint(buf_load16<0>(refs_d, best_ref).w);  // the hit record's id, read once at the end
     if (literal) {
         Counters ctr{};
-        got = trace_ray<WGSL, ANY, 0, false, false, false, 2>(s, o, rd, out, ctr);  // the form without an LDS buffer
+        got = trace_ray<WGSL, ANY, 0, false, TEX, false, 2>(s, o, rd, out, ctr);  // the form without an LDS buffer
     }
     return active && got;
 }

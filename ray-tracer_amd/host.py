@@ -388,7 +388,7 @@ class TraceCore:
             arr[i].rgba8, arr[i].width, arr[i].height = t.ctypes.data, t.shape[1], t.shape[0]
         self._ck(self._L.rt_set_textures(self._h, arr if keep else None, len(keep)))
 
-    def render(self, cam, width, height, shard=None, max_bounces=8, shadows=False, debug_pixel=None, out=None):
+    def render(self, cam, width, height, shard=None, max_bounces=8, shadows=False, debug_pixel=None, out=None, plain_bounces=False):
         """The shader's picture: (n_pixels, 4) uint8 RGBA, row-major (tile-packed with a shard). `out` may be a
         torch CUDA uint8 tensor / device pointer to keep it on the GPU."""
         n = shard_pixels(width, height, shard)
@@ -396,7 +396,7 @@ class TraceCore:
             out = np.empty((n, 4), np.uint8)
         o = RtRenderOpts()
         self._L.rt_default_render_opts(C.byref(o))
-        o.max_bounces, o.shadows = max_bounces, 1 if shadows else 0
+        o.max_bounces, o.shadows, o.plain_bounces = max_bounces, 1 if shadows else 0, 1 if plain_bounces else 0
         if debug_pixel is not None:
             o.debug_enabled, o.debug_pixel[0], o.debug_pixel[1] = 1, debug_pixel[0], debug_pixel[1]
         self._ck(self._L.rt_render(self._h, _ref(cam, CameraUniform), width, height, _ref(shard, RtShard), C.byref(o),

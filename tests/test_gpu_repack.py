@@ -122,3 +122,40 @@ def test_the_entry_point_that_allocates_nothing_deals_pairs_out_too(rt):
         assert_hits_equal(s1, s0, "shadow")
     finally:
         on.close(), off.close()
+
+
+def test_pictures_whose_bounce_rays_share_their_lists_equal_the_plain_ones(rt, ob, car_xyz9, phoenix_xyz9):
+    """rt_render with reflection bounces (k_render_deal) against rt_render_opts.plain_bounces = 1 (k_render) and the
+    oracle: the bundled models with their materials and textures (texture-decided alpha included), the same with every
+    material opaque, and without materials; 2 and 8 bounces, with and without the shadow term, shards."""
+    from render_scenes import bundled_model
+    for name, xyz9, pos, yaw, pitch in (("car", car_xyz9, (200, 200, 300), 3.35, -0.28), ("phoenix", phoenix_xyz9, (-300, 250, 600), 2.7, -0.2)):
+        tris, mats, textures = bundled_model(ob, name, xyz9)
+        opaque = mats.copy()
+        opaque["alpha_mode"] = 0
+        mirror = mats.copy()  # every surface reflects: long paths
+        mirror["metallic"] = 0.6
+        for what, m, tex in (("as loaded", mats, textures), ("opaque", opaque, textures), ("mirrors", mirror, textures), ("no materials", None, None)):
+            core = rt.TraceCore(0)
+            try:
+                core.set_scene(None, tris)
+                core.set_materials(m)
+                if tex is not None:
+                    core.set_textures(tex)
+                core.build_grid()
+                w, h = 240, 135
+                cam = rt.Camera(pos, yaw, pitch).to_uniform(0.0, float(h))
+                for bounces in (2, 8):
+                    for shadows in (False, True):
+                        a = core.render(cam, w, h, max_bounces=bounces, shadows=shadows)
+                        b = core.render(cam, w, h, max_bounces=bounces, shadows=shadows, plain_bounces=True)
+                        assert np.array_equal(a, b), f"{name} {what}: {bounces} bounces, shadows {shadows}"
+                shard = rt.RtShard(32, 32, 1, 3)
+                assert np.array_equal(core.render(cam, w, h, shard=shard), core.render(cam, w, h, shard=shard, plain_bounces=True)), f"{name} {what}: shard"
+                if what in ("mirrors", "no materials"):  # ("as loaded" against the oracle: tests/test_gpu_textures.py)
+                    scene = ob.Scene(None, tris, materials=m, textures=tex) if m is not None else ob.Scene(None, tris)
+                    want, _ = ob.render(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params), max_bounces=8, shadows=True)
+                    got = core.render(cam, w, h, max_bounces=8, shadows=True)
+                    assert np.array_equal(got, want), f"{name} {what}: against the oracle"
+            finally:
+                core.close()

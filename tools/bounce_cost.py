@@ -15,11 +15,15 @@ import ray_tracer_amd as rt  # noqa: E402
 from render_scenes import bundled_model  # noqa: E402
 
 W, H = 1920, 1080
+PLAIN = os.environ.get("RT_PLAIN_BOUNCES") == "1"  # rt_render_opts.plain_bounces: every ray scans its own lists
 core = rt.TraceCore(0)
 tris, mats, textures = bundled_model(rt, "car", np.load(os.path.join(ROOT, "tests/golden/car_tris.npy")))
 cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
 streams = [torch.cuda.Stream() for _ in range(2)]
 outs = [torch.empty((W * H, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+if os.environ.get("RT_ALPHA_OPAQUE") == "1":  # no hit is decided by a texture's alpha: the picture kernel that shares bounce rays' lists may run
+    mats = mats.copy()
+    mats["alpha_mode"] = 0
 core.set_scene(None, tris)
 core.set_materials(mats)
 core.set_textures(textures)
@@ -34,7 +38,7 @@ for bounces in (1, 2, 3, 4, 8):
     def frames(n):
         for k in range(n):
             core.set_stream(streams[k % 2].cuda_stream)
-            core.render(cam, W, H, max_bounces=bounces, shadows=False, out=outs[k % 2])
+            core.render(cam, W, H, max_bounces=bounces, shadows=False, out=outs[k % 2], plain_bounces=PLAIN)
         core.sync()
     frames(10)
     t0 = time.perf_counter()

@@ -818,6 +818,8 @@ void launch_rays(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const float
             hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, false, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
     } else if (s.nb != 0)
         hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
+    else if (c->params.repack_candidates && n != 0)
+        hipLaunchKernelGGL((k_trace_rays_repack<WGSL, ANY>), grid, dim3(256), 0, c->stream, s, o, d, n, out);
     else
         hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, false>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
 }

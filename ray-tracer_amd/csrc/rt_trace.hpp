@@ -1300,6 +1300,21 @@ __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __r
     if (STATS) flush_stats(stats, n_rays, n_hit, 0, 0, ctr);
 }
 
+// k_trace_rays with trace_ray_repack as the traversal (rt_params.repack_candidates): a caller's ray list is rarely
+// ordered so that neighbouring rays share their cells. Lanes past the end of the list take part without a ray.
+template <bool WGSL, bool ANY>
+__global__ __launch_bounds__(256, 6) void k_trace_rays_repack(DevScene s, const float* __restrict__ origins,
+                                                              const float* __restrict__ dirs, uint32_t n, uint2* __restrict__ out) {
+    __shared__ RepackLds repack[4];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool active = i < n;
+    const size_t at = active ? i : 0u;
+    const RayDir rd = make_ray_dir<WGSL>(ld3(dirs + 3 * at), s.cell_size, s.px, s.pxy);
+    HitRec h;
+    const bool hit = trace_ray_repack<WGSL, ANY>(s, ld3(origins + 3 * at), rd, active, h, repack[(threadIdx.x >> 6) & 3]);
+    if (active) out[i] = hit ? make_uint2(h.id, __float_as_uint(h.t)) : make_uint2(MISS, 0u);
+}
+
 // One pixel, one lane: what the shader writes for its debug pixel (:695-709), geometry fields.
 template <bool WGSL, bool WIDE = false>
 __global__ void k_debug_pixel(DevScene s, DevFrame f, uint32_t px, uint32_t py, float* __restrict__ info20) {

@@ -159,3 +159,30 @@ def test_pictures_whose_bounce_rays_share_their_lists_equal_the_plain_ones(rt, o
                     assert np.array_equal(got, want), f"{name} {what}: against the oracle"
             finally:
                 core.close()
+
+
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_ray_lists_in_no_order(rt, ob, any_hit):
+    """rt_trace_rays with repack_candidates: random origins and directions (a list no caller sorted), rays that miss the
+    grid, axis-parallel and zero directions, a count that is no multiple of 64 - against the plain kernel and the
+    oracle."""
+    xyz9 = random_soup(15000, 21)
+    on, off = pair(rt, rt.triangles_from_xyz9(xyz9), cell_size=4.0)
+    try:
+        rng = np.random.default_rng(4)
+        n = 20000 + 37
+        o = rng.uniform(-70, 70, (n, 3)).astype(np.float32)
+        d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[:6] = [(1, 0, 0), (0, -1, 0), (0, 0, 1), (0, 0, 0), (1, 1, 0), (0, 1e-30, 1)]
+        o[6:12] = [(200, 200, 200), (-200, 0, 0), (0, 0, 0), (55, 0, 0), (0, 300, 0), (10, 10, -300)]
+        a = on.trace_rays(o, d, any_hit=any_hit)
+        b = off.trace_rays(o, d, any_hit=any_hit)
+        assert_hits_equal(a, b, "pairs dealt out against the plain loop")
+        assert (a["id"] != rt.RT_MISS).sum() > 1000
+        scene = ob.Scene(None, ob.triangles_from_xyz9(xyz9), cell_size=4.0)
+        want = ob.trace_rays(scene, o, d, any_hit=any_hit, n_threads=8)
+        want = want[0] if isinstance(want, tuple) else want
+        assert_hits_equal(a, want, "against the oracle")
+    finally:
+        on.close(), off.close()

@@ -28,6 +28,13 @@ else:
     w, h, steps = 1920, 1080, 100
     tris = rt.triangles_from_xyz9(np.load(os.path.join(ROOT, f"tests/golden/{spec[0]}_tris.npy")))
     cam = (rt.Camera.for_scene("gltf") if spec[0] == "car" else rt.Camera((-300, 250, 600), 2.7, -0.2)).to_uniform(0.0, float(h))
+RAYS = os.environ.get("RT_RAYS") == "1"  # rt_trace_rays on 4 M rays with random origins and directions instead of a frame
+if RAYS:
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n_rays = 1 << 22
+    ray_o = (torch.rand((n_rays, 3), device="cuda", generator=g) * 100.0 - 50.0).contiguous()
+    ray_d = torch.nn.functional.normalize(torch.randn((n_rays, 3), device="cuda", generator=g), dim=1).contiguous()
+    w, h = n_rays, 1
 outs = {}
 times = {0: [], 1: []}
 cores = {}
@@ -41,14 +48,19 @@ for rnd in range(3):
     for repack in (0, 1):
         core = cores[repack]
         p, s = outs[repack]
+        def frame():
+            if RAYS:
+                core.trace_rays(ray_o, ray_d, out=p, n=n_rays)
+            else:
+                core.trace_primary(cam, w, h, out_primary=p, out_shadow=s)
         for _ in range(2):
-            core.trace_primary(cam, w, h, out_primary=p, out_shadow=s)
+            frame()
         core.sync()
         core.timer_begin()
         for _ in range(steps):
-            core.trace_primary(cam, w, h, out_primary=p, out_shadow=s)
+            frame()
         times[repack].append(core.timer_end() / steps * 1e3)
-same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+same = torch.equal(outs[0][0], outs[1][0]) and (RAYS or torch.equal(outs[0][1], outs[1][1]))
 print(f"{':'.join(spec)} {w}x{h}: records {'identical' if same else 'DIFFER'}")
 for repack in (0, 1):
     print(f"repack_candidates={repack}: {np.median(times[repack]):9.1f} us per frame (rounds: {', '.join(f'{t:.1f}' for t in times[repack])})")

@@ -49,6 +49,7 @@ def setup(spec):
         cam = rt.Camera((3.0, -2.0, 49.0), math.pi + 0.2, -0.1)
     else:
         raise SystemExit(f"unknown scene {spec}")
+    params.repack_candidates = int(os.environ.get("RT_REPACK", "0"))  # rt_params.repack_candidates
     core = rt.TraceCore(0, params)
     core.set_scene(None, tris)
     core.build_grid(cell_size=cell)

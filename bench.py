@@ -265,6 +265,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` started plainly (no launcher, WORLD_SIZE unset): this process becomes the launcher. It
+    # starts torch.distributed.run as a CHILD with one rank per GPU, hands its stdout (the one JSON line of rank 0) and
+    # stderr through, and exits with the child's code. Decided here, before anything has touched a GPU.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+               "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        raise SystemExit(subprocess.call(cmd))
+
     import torch.distributed as dist
 
     # The contract is ONE line on stdout. Libraries print there too (RCCL writes a version banner when its first
@@ -289,6 +305,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("RT_BENCH_DRY_RUN") == "1":  # the launch path alone, on CPU (tests): rendezvous, one collective, one line
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        if rank == 0:
+            emit(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(ones.item()), "steps": args.steps, "warmup": args.warmup}))
+        dist.destroy_process_group()
+        return
     # Rehearsal on a one-GPU box: RT_BENCH_ONE_GPU=1 puts every rank on GPU 0 and uses gloo (RCCL refuses two
     # ranks on one device). Never set by the driver.
     rehearsal = os.environ.get("RT_BENCH_ONE_GPU") == "1"
@@ -517,6 +543,8 @@ def main():
                                     f"{GROUP} frames, RGB8, assembled to RGBA8, no collective")
         if multi and base_ms:
             out["speedup_vs_scaling_base"] = base_ms / ms_per_step
+        if multi:  # false: the gathers of this line are torch.distributed's (or the rehearsal's), not rt_gather_frames
+            out["native_comm"] = bool(getattr(core, "comm_size", 0))
         out["timed_kernel"] = ("k_trace_primary_lean<shadow>: rt_hit records" if not multi else
                                "k_render<single bounce, shadow term>: RGB8 picture, "
                                + ("rt_gather_frames (RCCL through the C ABI)" if getattr(core, "comm_size", 0) else

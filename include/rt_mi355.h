@@ -226,6 +226,13 @@ int rt_get_heavy_blocks(rt_ctx* ctx, uint32_t* n_heavy, uint32_t* n_early, uint3
  * reference counterpart. */
 int rt_get_cull_stats(rt_ctx* ctx, uint32_t* blocks_total, uint32_t* blocks_kept);
 
+/* Checked builds only (make -C ray-tracer_amd/csrc checked -> librt_mi355_checked.so: the trace kernels compare every
+ * record, cell and triangle index they form with the array it addresses, count violations instead of faulting, and go
+ * on): how many violations the launches of this process have counted so far, and the first one's kind and two
+ * operands (first3 may be NULL). Waits for the device. The shipped library compiles no checks and returns
+ * RT_ERR_STATE. No reference counterpart (the reference relies on the shader compiler's robust buffer access). */
+int rt_checked_violations(rt_ctx* ctx, uint32_t* count, uint32_t first3[3]);
+
 /* How the current grid was made: 0 = rt_build_grid's general path (sizes read back by the host between passes,
  * duplicate search, any scene), 1 = its rebuild path for scenes of up to 65 536 objects whose grid has been built
  * before with the same mode, cell size and cap (rt_update_vertices / rt_skin_vertices + rt_build_grid, the animated

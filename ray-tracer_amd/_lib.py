@@ -154,6 +154,7 @@ PROTOTYPES = {
     "rt_set_materials": (_I, [_VP, _VP, _U32]),
     "rt_get_heavy_blocks": (_I, [_VP, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
     "rt_get_cull_stats": (_I, [_VP, C.POINTER(_U32), C.POINTER(_U32)]),
+    "rt_checked_violations": (_I, [_VP, C.POINTER(_U32), C.POINTER(_U32 * 3)]),
     "rt_trace_primary_frames": (_I, [_VP, _VP, _U32, _U32, _U32, C.POINTER(RtShard), _VP, _VP, C.c_size_t]),
     "rt_get_build_path": (_I, [_VP, C.POINTER(_I)]),
     "rt_get_trace_refs": (_I, [_VP, C.POINTER(C.c_uint32)]),

@@ -1221,6 +1221,22 @@ extern "C" int rt_get_cull_stats(rt_ctx* c, uint32_t* blocks_total, uint32_t* bl
     return RT_OK;
 }
 
+extern "C" int rt_checked_violations(rt_ctx* c, uint32_t* count, uint32_t first3[3]) {
+    if (int r = use(c)) return r;
+    if (!count) return fail(c, RT_ERR_INVALID, "rt_checked_violations: count is NULL");
+#ifdef RT_CHECKED
+    uint32_t v[4] = {0, 0, 0, 0};
+    RT_HIP(c, hipDeviceSynchronize());
+    RT_HIP(c, hipMemcpyFromSymbol(v, HIP_SYMBOL(rt::g_check), sizeof(v)));
+    *count = v[0];
+    if (first3) first3[0] = v[1], first3[1] = v[2], first3[2] = v[3];
+    return RT_OK;
+#else
+    *count = 0;
+    return fail(c, RT_ERR_STATE, "rt_checked_violations: this library was built without index checks (make checked)");
+#endif
+}
+
 extern "C" int rt_get_heavy_blocks(rt_ctx* c, uint32_t* n_heavy, uint32_t* n_early, uint32_t* threshold_us) {
     if (int r = use(c)) return r;
     if (!n_heavy) return fail(c, RT_ERR_INVALID, "rt_get_heavy_blocks: NULL argument");

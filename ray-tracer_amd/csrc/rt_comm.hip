@@ -15,6 +15,7 @@
 // would bring a second HIP runtime into the process.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include <rccl/rccl.h>
@@ -47,7 +48,8 @@ const RcclApi* rccl() {
     std::lock_guard<std::mutex> hold(g_rccl_lock);
     if (g_rccl.handle) return &g_rccl;
     if (!g_rccl.error.empty()) return nullptr;
-    // a copy that is already in the process first (RTLD_NOLOAD), then the system's
+    // a copy that is already in the process first (RTLD_NOLOAD), then the system's. RT_RCCL_LIBRARY names the one
+    // library to bind instead (a site's own build; the tests use it to reach the not-found path).
     const struct {
         const char* name;
         int flags;
@@ -55,10 +57,16 @@ const RcclApi* rccl() {
                  {"librccl.so.1", RTLD_NOW | RTLD_GLOBAL}, {"librccl.so", RTLD_NOW | RTLD_GLOBAL},
                  {"/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL}};
     void* h = nullptr;
-    for (const auto& t : tries)
-        if ((h = dlopen(t.name, t.flags))) break;
+    const char* only = getenv("RT_RCCL_LIBRARY");
+    if (only && *only) {
+        h = dlopen(only, RTLD_NOW | RTLD_GLOBAL);
+    } else {
+        for (const auto& t : tries)
+            if ((h = dlopen(t.name, t.flags))) break;
+    }
     if (!h) {
-        g_rccl.error = std::string("RCCL not found (librccl.so / librccl.so.1): ") + (dlerror() ? dlerror() : "");
+        const char* why = dlerror();  // one call: it hands the message over and clears it
+        g_rccl.error = std::string("RCCL not found (") + (only && *only ? only : "librccl.so / librccl.so.1") + "): " + (why ? why : "");
         return nullptr;
     }
     bool ok = true;
@@ -155,18 +163,23 @@ extern "C" int rt_comm_info(rt_ctx* c, int* rank, int* n_ranks) {
     return RT_OK;
 }
 
+// A collective: every rank must reach the first broadcast whatever its own arguments look like, or the others wait in it
+// for ever. So the root's argument checks do not return early: a root that cannot go on says so IN the counts word
+// ({0xFFFFFFFF, -status}), and every rank returns that status after the broadcast.
 extern "C" int rt_broadcast_scene(rt_ctx* c, int root, const BoxData* boxes, uint32_t nb, const TriangleData* tris, uint32_t nt) {
     const RcclApi* api = nullptr;
     if (int r = with_comm(c, "rt_broadcast_scene", &api)) return r;
     if (root < 0 || root >= c->comm_size) return fail(c, RT_ERR_INVALID, "rt_broadcast_scene: root %d of %d ranks", root, c->comm_size);
     const bool is_root = c->comm_rank == root;
-    if (is_root && ((nb && !boxes) || (nt && !tris))) return fail(c, RT_ERR_INVALID, "rt_broadcast_scene: NULL array with non-zero count");
-    if (is_root && (uint64_t)nb + nt >= 0xFFFFFFF0ull) return fail(c, RT_ERR_LIMIT, "rt_broadcast_scene: more than 2^32-16 objects");
-    if (int r = begin_scene(c)) return r;
+    int root_status = RT_OK;
+    if (is_root && ((nb && !boxes) || (nt && !tris))) root_status = RT_ERR_INVALID;
+    if (is_root && (uint64_t)nb + nt >= 0xFFFFFFF0ull) root_status = RT_ERR_LIMIT;
+    if (int r = begin_scene(c)) root_status = is_root ? r : root_status;
     ncclComm_t comm = static_cast<ncclComm_t>(c->comm);
     // sizes first: two words, device to device, read back by the ranks that do not know them yet
     RT_HIP(c, c->stats.reserve(16 * sizeof(unsigned long long)));
     uint32_t counts[2] = {nb, nt};
+    if (root_status != RT_OK) counts[0] = 0xFFFFFFFFu, counts[1] = (uint32_t)(-root_status);
     if (is_root) RT_HIP(c, hipMemcpyAsync(c->stats.p, counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
     RT_NCCL(c, api, api->Broadcast(c->stats.p, c->stats.p, sizeof(counts), ncclUint8, root, comm, c->stream));
     if (!is_root) {
@@ -174,6 +187,13 @@ extern "C" int rt_broadcast_scene(rt_ctx* c, int root, const BoxData* boxes, uin
         RT_HIP(c, hipStreamSynchronize(c->stream));
         nb = counts[0];
         nt = counts[1];
+    }
+    if (counts[0] == 0xFFFFFFFFu) {
+        const int status = -(int)counts[1];
+        if (!is_root) return fail(c, status, "rt_broadcast_scene: rank %d (the root) could not send its scene (status %d)", root, status);
+        if (status == RT_ERR_LIMIT) return fail(c, status, "rt_broadcast_scene: more than 2^32-16 objects");
+        if (status == RT_ERR_INVALID) return fail(c, status, "rt_broadcast_scene: NULL array with non-zero count");
+        return status;  // begin_scene's own message stands
     }
     if (int r = reserve_scene(c, nb, nt)) return r;
     // the root's arrays cross PCIe once, into the very buffers the broadcast then replicates

@@ -32,6 +32,27 @@ constexpr uint32_t CELL_SENTINEL = 0xFFFFFFFFu;  // count of a border cell: the 
 constexpr uint32_t BOX_CULLED_GRID = 1u;       // LOD cull outcome when met through a grid cell
 constexpr uint32_t BOX_CULLED_PREPASS = 2u;    // LOD cull outcome in the moving-box pre-pass
 
+// Checked build (make -C ray-tracer_amd/csrc checked: -DRT_CHECKED, rt_api.hip only): every index the traversal forms
+// is compared with the array it is about to read - reference record against the records built, flattened cell index
+// against the bordered cell array, triangle id against the triangle count, staging slot against the LDS buffer. A
+// violation is COUNTED (g_check[0]; the first one's kind and operands in [1..3]) and reported by rt_checked_violations;
+// it never traps, so a bug found this way costs a failed test, not a GPU fault. The shipped build compiles none of it.
+#ifdef RT_CHECKED
+__device__ uint32_t g_check[4];
+__device__ inline void check_failed(uint32_t kind, uint32_t a, uint32_t b) {
+    if (atomicAdd(&g_check[0], 1u) == 0u) g_check[1] = kind, g_check[2] = a, g_check[3] = b;
+}
+#define RT_CHECK(cond, kind, a, b)                \
+    do {                                          \
+        if (!(cond)) check_failed((kind), (a), (b)); \
+    } while (0)
+#else
+#define RT_CHECK(cond, kind, a, b) \
+    do {                           \
+    } while (0)
+#endif
+constexpr uint32_t CHECK_REF = 1, CHECK_CELL = 2, CHECK_TRIANGLE = 3, CHECK_STAGE = 4, CHECK_DEAL = 5;
+
 struct DevScene {
     const float4* refs;
     const uint2* cells;
@@ -210,6 +231,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
     const v4i cells_d = make_rsrc(s.cells, 8, s.n_bordered);
     auto ref_quad = [&](uint32_t r, auto quad) -> float4 {
         constexpr int Q = decltype(quad)::value;
+        RT_CHECK(r <= s.n_refs + (QCAP ? 4u : 0u), CHECK_REF, r, s.n_refs);  // one record of padding; the quad form's look-ahead reads zeros
         if constexpr (WIDE)
             return s.refs[3 * (size_t)r + Q];
         else
@@ -221,6 +243,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
             if (__builtin_amdgcn_ballot_w64(idx == first) == __builtin_amdgcn_ballot_w64(true)) ctr.cell_recs_uniform++;
         }
+        RT_CHECK(idx < s.n_bordered, CHECK_CELL, idx, s.n_bordered);
         if constexpr (WIDE)
             return s.cells[idx];
         else
@@ -308,6 +331,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
             }
         } else {
             if (STATS == 1 && id != REF_INVALID) ctr.tri++;
+            RT_CHECK(id >= REF_INVISIBLE || id - s.nb < s.nt, CHECK_TRIANGLE, id, s.nt);
             const float t = moller_trumbore_pk<WGSL>(rp, c0, c1, c2);
             if (t > 0.0f && t < closest && id < REF_INVISIBLE) {
                 if (TEX && __float_as_uint(c2.w) != 0u) {
@@ -349,6 +373,7 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
                     const uint32_t cnt = n0 - base < STAGE_RECORDS ? n0 - base : STAGE_RECORDS;
                     for (uint32_t k = rank; k < cnt; k += n_act) {
                         if (STATS == 2) ctr.staged_recs++;
+                        RT_CHECK(k < STAGE_RECORDS, CHECK_STAGE, k, cnt);
                         mine[3 * k] = ref_quad(r0 + base + k, Q0{});
                         mine[3 * k + 1] = ref_quad(r0 + base + k, Q1{});
                         mine[3 * k + 2] = ref_quad(r0 + base + k, Q2{});
@@ -919,6 +944,7 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
         const bool az = !ax && !ay;
         const float t_exit = fminf(fminf(t_max.x, t_max.y), t_max.z);
         const uint32_t idx_next = alive ? idx + (ax ? dix : (ay ? diy : diz)) : 0u;
+        RT_CHECK(idx_next < s.n_bordered, CHECK_CELL, idx_next, s.n_bordered);
         const uint2 cell_next = buf_load8(cells_d, idx_next);
         const uint32_t n = alive ? cell.y : 0u;
         const uint32_t incl = wave_prefix_sum(n);
@@ -978,6 +1004,7 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
                     const uint32_t k = p - L.excl[j];
                     const float4 df = L.d_first[j];
                     const uint32_t rec = __float_as_uint(df.w) + k;
+                    RT_CHECK(j < 64u && rec < s.n_refs, CHECK_DEAL, j, rec);
                     const float4 c0 = buf_load16<0>(refs_d, rec), c1 = buf_load16<16>(refs_d, rec), c2 = buf_load16<32>(refs_d, rec);
                     const float4 oa = L.o_arrival[j];
                     if (!(__float_as_uint(c1.w) & __float_as_uint(oa.w))) {

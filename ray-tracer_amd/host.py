@@ -213,6 +213,16 @@ class TraceCore:
         self._ck(self._L.rt_get_cull_stats(self._h, C.byref(n), C.byref(k)))
         return n.value, k.value
 
+    def checked_violations(self):
+        """(count, (kind, a, b)) from a checked build of the library (RT_LIB_PATH=.../librt_mi355_checked.so): index
+        violations its trace kernels have counted in this process; None from the shipped library, which has no checks."""
+        n, first = C.c_uint32(), (C.c_uint32 * 3)()
+        rc = self._L.rt_checked_violations(self._h, C.byref(n), C.byref(first))
+        if rc == -4:  # RT_ERR_STATE: not a checked build
+            return None
+        self._ck(rc)
+        return n.value, tuple(first)
+
     def build_path(self):
         """0: general build, 1: rebuild with every size kept on the device, -1: grid supplied by the caller."""
         v = C.c_int()

@@ -74,10 +74,21 @@ def init_comm(core, rank=None, world=None, src=0):
     rt_broadcast_scene: RCCL on the trace core's own stream, device to device, no torch tensors in the data path."""
     rank = dist.get_rank() if rank is None else rank
     world = dist.get_world_size() if world is None else world
-    box = [core.comm_unique_id() if rank == src else None]
+    # ncclCommInitRank is itself a collective, and so is handing the id round: a rank that cannot bind RCCL must not
+    # leave the others waiting in either. Every rank first tries to make an id (which binds the library and touches
+    # nothing else), the outcomes are exchanged, and all ranks raise together or go on together.
+    try:
+        mine = ("ok", core.comm_unique_id())
+    except Exception as e:  # noqa: BLE001
+        mine = ("error", f"rank {rank}: {e}")
+    everyone = [mine]
     if world > 1:
-        dist.broadcast_object_list(box, src=src)
-    core.comm_init(box[0], rank, world)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+    bad = [m for status, m in everyone if status != "ok"]
+    if bad:
+        raise RuntimeError("no RCCL communicator: " + "; ".join(bad))
+    core.comm_init(everyone[src][1], rank, world)
 
 
 def replicate_scene(core, boxes, tris, src=0):

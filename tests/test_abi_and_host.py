@@ -118,3 +118,17 @@ def test_product_package_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle"
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """Without an RCCL to bind the multi-GPU entry points return RT_ERR_COMM (include/rt_mi355.h): the process must
+    survive to take another route. RT_RCCL_LIBRARY names the one library to bind; the binding is cached per process,
+    hence the child."""
+    prog = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from ray_tracer_amd import _lib\n"
+            "L = _lib.load(); buf = (C.c_uint8 * _lib.RT_COMM_ID_BYTES)()\n"
+            "print(L.rt_comm_unique_id(buf), L.rt_comm_unique_id(buf))\n" % ROOT)
+    env = dict(os.environ, RT_RCCL_LIBRARY="/nonexistent/librccl-none.so")
+    out = subprocess.run([os.sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["-6", "-6"], out.stdout

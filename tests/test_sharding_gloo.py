@@ -187,3 +187,73 @@ def test_tile_bookkeeping():
             mine = [shard_pixels(w, h, RtShard(tw, th, r, world)) for r in range(world)]
             assert max(mine) == per or nt < world  # the padded block holds the busiest rank's tiles
             assert sum(mine) == nt * tw * th       # every tile is traced exactly once
+
+
+def test_bench_starts_its_own_ranks_when_run_plainly():
+    """`python bench.py --gpus 2` without a launcher (WORLD_SIZE unset) must start its ranks itself and still print
+    exactly one JSON line on stdout; under torch.distributed.run it must not start a second set. RT_BENCH_DRY_RUN stops
+    each rank after the rendezvous and one collective, so this runs without a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["RT_BENCH_DRY_RUN"] = "1"
+    bench = os.path.join(ROOT, "bench.py")
+    plain = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "7", "--warmup", "3"], env=env, capture_output=True,
+                           text=True, timeout=300)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    lines = [ln for ln in plain.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, plain.stdout
+    got = json.loads(lines[0])
+    assert got == {"dry_run": True, "n_gpus": 2, "ranks_seen": 2, "steps": 7, "warmup": 3}
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                               "127.0.0.1", "--master-port", str(_free_port()), bench, "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                              env=env, capture_output=True, text=True, timeout=300)
+    assert launched.returncode == 0, launched.stderr[-3000:]
+    lines = [ln for ln in launched.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2, launched.stdout
+    # a world size that disagrees with --gpus is refused, loudly
+    wrong = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True,
+                           text=True, timeout=300)
+    assert wrong.returncode != 0 and "WORLD_SIZE" in wrong.stderr
+
+
+class _CommCore:
+    """Stands in for TraceCore's communicator calls: rank `bad` cannot bind RCCL."""
+
+    def __init__(self, rank, bad):
+        self.rank, self.bad, self.inited = rank, bad, None
+
+    def comm_unique_id(self):
+        if self.rank == self.bad:
+            raise RuntimeError("RCCL not found")
+        return bytes([self.rank + 1]) * 128
+
+    def comm_init(self, comm_id, rank, world):
+        self.inited = (bytes(comm_id), rank, world)
+
+
+def _comm_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ray_tracer_amd import sharding
+        good = _CommCore(rank, bad=-1)
+        sharding.init_comm(good, rank, world)
+        assert good.inited == (bytes([1]) * 128, rank, world)  # rank 0's id on every rank
+        broken = _CommCore(rank, bad=1)
+        try:
+            sharding.init_comm(broken, rank, world)
+            raised = ""
+        except RuntimeError as e:
+            raised = str(e)
+        assert "rank 1" in raised and broken.inited is None  # EVERY rank raises, none is left waiting in a collective
+        dist.barrier()
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("1")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_without_rccl_stops_every_rank_together(tmp_path):
+    mp.spawn(_comm_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()

@@ -594,6 +594,14 @@ def main():
             if os.environ.get("RT_BENCH_LEG", "both") != "headline" and WORKLOAD == "car1080":
                 core.close()
                 out["roofline_streaming"] = streaming_leg(rt, dev, int(os.environ.get("RT_BENCH_STREAM_STEPS", "20")), 3)
+            # the other BASELINE configurations on this GPU, one bounded leg each (tools/config_legs.py); RT_BENCH_CONFIGS=0
+            # leaves them out (profiling runs of the headline kernel)
+            if WORKLOAD == "car1080" and os.environ.get("RT_BENCH_CONFIGS", "1") != "0" and os.environ.get("RT_BENCH_LEG", "both") == "both":
+                if core._h:
+                    core.close()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import config_legs
+                out["configs"], out["configs_wall_s"] = config_legs.all_legs(rt, dev)
             if not args.no_cpu_baseline and xyz9 is not None:
                 out["cpu_baseline"] = cpu_baseline(xyz9, WIDTH, HEIGHT)
         emit(json.dumps(out))

@@ -14,6 +14,7 @@ pub struct RtParams {
     pub finest_cell_size: f32, pub max_objects_per_cell: u32, pub max_dda_steps: u32, pub wgsl_compat: u32,
     pub lod_cull: u32, pub moving_box_count: u32, pub fov: f32, pub light_direction: [f32; 3],
     pub shadow_offset: f32, pub collect_stats: u32, pub skip_duplicate_triangles: u32, pub heavy_block_threshold: u32, pub cull_empty_blocks: u32, pub repack_candidates: u32,
+    pub persistent_waves: u32,
 }
 
 #[repr(C)]
@@ -22,6 +23,12 @@ pub struct RtShard { pub tile_w: u32, pub tile_h: u32, pub first: u32, pub strid
 
 #[repr(C)]
 pub struct RtCtx { _private: [u8; 0] }
+
+// The table at the end of include/rt_mi355.h (RT_SIZEOF_*), which the C / C++ compiler checks against the header's own
+// structs: a struct that grows there without growing here stops this crate from compiling instead of corrupting memory.
+const _: () = assert!(std::mem::size_of::<RtParams>() == 68);
+const _: () = assert!(std::mem::size_of::<RtShard>() == 24);
+const _: () = assert!(std::mem::size_of::<RtHit>() == 8);
 
 extern "C" {
     pub fn rt_default_params(p: *mut RtParams);

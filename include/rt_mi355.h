@@ -118,6 +118,16 @@ typedef struct rt_params {
                                          (104 against 130 us), hence 0 by default. Triangle-only scenes with up to 4 GiB
                                          of reference records, no counters, no texture-decided hits, no plan of
                                          expensive blocks; ignored elsewhere. No reference counterpart */
+    uint32_t persistent_waves;      /* 1: rt_trace_primary launches as many workgroups as the GPU holds at once and each
+                                         workgroup takes 8x8 pixel blocks from a queue (an atomic counter, sixteen blocks a turn)
+                                         until the frame is done, instead of one workgroup per 16x16 pixels dealt out by
+                                         the hardware dispatcher. The same records bit for bit. Measured slower than the
+                                         plain launch wherever tried (the dispatcher already hands a workgroup to whichever
+                                         slot frees first; the queue adds its atomics and, because the block body sits in
+                                         a loop, seven resident waves per SIMD instead of eight), hence 0 by default; for
+                                         callers that must bound the number of workgroups in flight. Triangle-only
+                                         scenes, no counters, no texture-decided hits, no plan of expensive blocks, at most
+                                         eight streams per context; ignored elsewhere. No reference counterpart */
 } rt_params;
 
 /* Which pixels of a W x H frame one call traces. The frame is cut into
@@ -510,6 +520,31 @@ int rt_probe_copy(rt_ctx* ctx, const void* src, void* dst, size_t bytes);
 
 #ifdef __cplusplus
 }
+#endif
+
+/* ---- layout of the structs this header adds -------------------------------------------- */
+/* A binding in another language (ffi/src/lib.rs, the ctypes views in ray-tracer_amd/_lib.py and oracle/binding.py)
+ * re-declares these structs by hand. The sizes below are what such a binding asserts on its own side
+ * (Rust: `const _: () = assert!(size_of::<RtParams>() == 68);`); they are checked here by the C or C++ compiler
+ * that reads this header, so header and table cannot drift apart, and tests/test_abi_and_host.py compares the
+ * ctypes views with them. All fields are 4- or 8-byte scalars in declaration order, no packing pragma. */
+#define RT_SIZEOF_PARAMS 68
+#define RT_SIZEOF_SHARD 24
+#define RT_SIZEOF_HIT 8
+#define RT_SIZEOF_STATS 88
+#define RT_SIZEOF_RENDER_OPTS 32
+#define RT_SIZEOF_TEXTURE 16
+#define RT_SIZEOF_BVH_STATS 32
+#if defined(__cplusplus)
+static_assert(sizeof(rt_params) == RT_SIZEOF_PARAMS && sizeof(rt_shard) == RT_SIZEOF_SHARD && sizeof(rt_hit) == RT_SIZEOF_HIT &&
+                  sizeof(rt_stats) == RT_SIZEOF_STATS && sizeof(rt_render_opts) == RT_SIZEOF_RENDER_OPTS &&
+                  sizeof(rt_texture) == RT_SIZEOF_TEXTURE && sizeof(rt_bvh_stats) == RT_SIZEOF_BVH_STATS,
+              "struct layout differs from the table other languages' bindings assert");
+#elif defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L
+_Static_assert(sizeof(rt_params) == RT_SIZEOF_PARAMS && sizeof(rt_shard) == RT_SIZEOF_SHARD && sizeof(rt_hit) == RT_SIZEOF_HIT &&
+                   sizeof(rt_stats) == RT_SIZEOF_STATS && sizeof(rt_render_opts) == RT_SIZEOF_RENDER_OPTS &&
+                   sizeof(rt_texture) == RT_SIZEOF_TEXTURE && sizeof(rt_bvh_stats) == RT_SIZEOF_BVH_STATS,
+               "struct layout differs from the table other languages' bindings assert");
 #endif
 
 #endif /* RT_MI355_H */

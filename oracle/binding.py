@@ -53,7 +53,7 @@ class Params(C.Structure):
                 ("fov", C.c_float), ("light_direction", C.c_float * 3), ("shadow_offset", C.c_float),
                 ("collect_stats", C.c_uint32), ("skip_duplicate_triangles", C.c_uint32),
                 ("heavy_block_threshold", C.c_uint32), ("cull_empty_blocks", C.c_uint32),
-                ("repack_candidates", C.c_uint32)]  # the last four: the GPU library's own, nothing the oracle reads
+                ("repack_candidates", C.c_uint32), ("persistent_waves", C.c_uint32)]  # the last five: the GPU library's own, nothing the oracle reads
 
     @classmethod
     def default(cls, **kw):

@@ -56,7 +56,7 @@ class RtParams(C.Structure):
                 ("wgsl_compat", C.c_uint32), ("lod_cull", C.c_uint32), ("moving_box_count", C.c_uint32),
                 ("fov", C.c_float), ("light_direction", C.c_float * 3), ("shadow_offset", C.c_float),
                 ("collect_stats", C.c_uint32), ("skip_duplicate_triangles", C.c_uint32), ("heavy_block_threshold", C.c_uint32), ("cull_empty_blocks", C.c_uint32),
-                ("repack_candidates", C.c_uint32)]
+                ("repack_candidates", C.c_uint32), ("persistent_waves", C.c_uint32)]
 
 
 class RtShard(C.Structure):

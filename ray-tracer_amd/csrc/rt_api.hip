@@ -688,6 +688,29 @@ int cull_mask_for(rt_ctx* c, const DevScene& s, const DevFrame& f, const ShardMa
     return cull_masks_for(c, s, &f, 1, m, mask, nullptr, always);
 }
 
+// The block-queue counter of the current stream (rt_params.persistent_waves); *queue stays null when eight other streams
+// hold the context's counters already: the caller then launches the plain grid.
+int queue_for(rt_ctx* c, uint32_t** queue) {
+    *queue = nullptr;
+    rt_queues& q = c->queues;
+    if (!q.counters.p) {
+        RT_HIP(c, q.counters.reserve(8 * 128));
+        RT_HIP(c, hipMemsetAsync(q.counters.p, 0, 8 * 128, c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));  // once per context: every stream's counter starts at zero
+        hipDeviceProp_t prop;
+        RT_HIP(c, hipGetDeviceProperties(&prop, c->device));
+        q.resident_wgs = (uint32_t)prop.multiProcessorCount * 6u;  // 4 SIMDs x 6 waves (the kernel holds up to 75 vector registers) = 6 workgroups of 4 waves per CU
+    }
+    int i = 0;
+    while (i < q.used && q.streams[i] != c->stream) ++i;
+    if (i == q.used) {
+        if (q.used == 8) return RT_OK;
+        q.streams[q.used++] = c->stream;
+    }
+    *queue = q.counters.as<uint32_t>() + 32 * i;
+    return RT_OK;
+}
+
 // Kernel variants: WGSL (constant set), SHADOW / ANY, BOXES (scene has boxes), TEX (hits decided by a texture's
 // alpha). The counting build is the general one (with the box path); so is the build for grids of 4 GiB and more.
 template <bool WGSL, bool SHADOW>
@@ -700,16 +723,25 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
         if (!WGSL && SHADOW && !stats && s.nb == 0) {
             const int vn = atoi(v);
             if (vn >= 40 && vn < 60) {  // persistent waves: one wave per wave slot of the chip
-                void* q = nullptr;
-                if (hipGetSymbolAddress(&q, HIP_SYMBOL(rt::g_queue)) != hipSuccess) return RT_OK;
+                void* q0 = nullptr;
+                if (hipGetSymbolAddress(&q0, HIP_SYMBOL(rt::g_queue)) != hipSuccess) return RT_OK;
+                static hipStream_t q_streams[8];  // a counter per launching stream: frames in flight must not share one
+                static int q_used = 0;
+                int qi = 0;
+                while (qi < q_used && q_streams[qi] != c->stream) ++qi;
+                if (qi == q_used) {
+                    if (q_used == 8) return fail(c, RT_ERR_LIMIT, "persistent variants: more than 8 streams");
+                    q_streams[q_used++] = c->stream;
+                }
+                uint32_t* q = static_cast<uint32_t*>(q0) + 32 * qi;
                 (void)hipMemsetAsync(q, 0, sizeof(uint32_t), c->stream);
                 const uint32_t n_waves = grid.x * 4;
                 switch (vn) {
-                    case 41: hipLaunchKernelGGL((k_trace_primary_persist<41>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
-                    case 44: hipLaunchKernelGGL((k_trace_primary_persist<44>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
-                    case 40: hipLaunchKernelGGL((k_trace_primary_persist<40>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
-                    case 54: hipLaunchKernelGGL((k_trace_primary_persist<54>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
-                    default: hipLaunchKernelGGL((k_trace_primary_persist<50>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves); break;
+                    case 41: hipLaunchKernelGGL((k_trace_primary_persist<41>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves, q); break;
+                    case 44: hipLaunchKernelGGL((k_trace_primary_persist<44>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves, q); break;
+                    case 40: hipLaunchKernelGGL((k_trace_primary_persist<40>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves, q); break;
+                    case 54: hipLaunchKernelGGL((k_trace_primary_persist<54>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves, q); break;
+                    default: hipLaunchKernelGGL((k_trace_primary_persist<50>), dim3(2048), dim3(256), 0, c->stream, s, f, m, op, os, n_waves, q); break;
                 }
                 return RT_OK;
             }
@@ -768,7 +800,28 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
         rt_plan* plan = nullptr;
         if (may_alloc && c->params.heavy_block_threshold && (uint64_t)grid.x * 4 + PLAN_LEAD_WGS < 0x7FFFFFFFull)
             if (int r = plan_for(c, m, f, grid.x * 4, SHADOW, &plan)) return r;
-        if (!plan && c->params.repack_candidates) {
+        uint32_t* queue = nullptr;
+        if (!plan && !c->params.repack_candidates && c->params.persistent_waves && may_alloc)
+            if (int r = queue_for(c, &queue)) return r;
+        if (queue) {
+            // persistent waves: as many workgroups as fit the device at once work the block queue off; the launch leaves
+            // the queue's counter at zero for the next one on this stream
+            const uint32_t* mask = nullptr;
+            if (int r = cull_mask_for(c, s, f, m, &mask, false)) return r;
+            QueueArgs a;
+            a.s = s, a.f = f, a.m = m, a.out_p = op, a.out_s = os, a.cull_mask = mask, a.queue = queue, a.n_waves = grid.x * 4u;
+            a.cull_zero = nullptr, a.cull_zero_words = 0;
+            if (mask) {  // the other buffer of the mask pair, for the next frame's mask: this launch zeroes it
+                rt_cull* k = c->last_cull;
+                a.cull_zero = k->buf[k->cur ^ 1].as<uint32_t>();
+                a.cull_zero_words = k->dirty[k->cur ^ 1];
+                k->dirty[k->cur ^ 1] = 0;
+            }
+            const uint32_t wgs = grid.x < c->queues.resident_wgs ? grid.x : c->queues.resident_wgs;
+            hipLaunchKernelGGL((k_trace_primary_queue<WGSL, SHADOW>), dim3(wgs), dim3(256), 0, c->stream, a);
+            if (c->params.cull_empty_blocks == 1)
+                if (int r = mark_in_flight(c)) return r;
+        } else if (!plan && c->params.repack_candidates) {
             // rays of a wave in different cells: (ray, candidate) pairs dealt out again to the lanes (trace_ray_repack)
             hipLaunchKernelGGL((k_trace_primary_repack<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os);
         } else if (plan) {
@@ -918,6 +971,7 @@ extern "C" void rt_default_params(rt_params* p) {
     p->heavy_block_threshold = 0;
     p->cull_empty_blocks = 1;
     p->repack_candidates = 0;
+    p->persistent_waves = 0;
 }
 
 extern "C" const char* rt_create_error(void) { return g_create_error.c_str(); }
@@ -982,6 +1036,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)rt_comm_destroy(c);
+    c->queues.counters.release();
     DevBuf* bufs[] = {&c->boxes,     &c->tri_v,     &c->tri_n,     &c->tri_mat,   &c->materials, &c->skin_pos, &c->skin_joints,
                       &c->skin_weights, &c->skin_tri, &c->skin_mats, &c->bvh_nodes, &c->bvh_leaf_first, &c->bvh_prims, &c->bvh_recs,     &c->cell_start, &c->indices,   &c->cells,       &c->refs,
                       &c->box_frame, &c->b_partial, &c->b_counts,   &c->b_tmp_start, &c->b_cursor,  &c->b_tmp_ids,
@@ -1411,7 +1466,7 @@ extern "C" int rt_trace_primary_frames(rt_ctx* c, const CameraUniform* cams, uin
     const DevScene s = make_scene(c);
     const bool host_out = !is_device_ptr(out_primary) || (out_shadow && !is_device_ptr(out_shadow));
     const bool grouped = !c->params.collect_stats && c->grid_nb == 0 && c->tex_mode != 2 && !wide_grid(s) &&
-                         !c->params.heavy_block_threshold && !c->params.repack_candidates && !host_out && n_frames > 1;
+                         !c->params.heavy_block_threshold && !c->params.repack_candidates && !c->params.persistent_waves && !host_out && n_frames > 1;
     if (!grouped) {
         for (uint32_t j = 0; j < n_frames; ++j)
             if (int r = trace_primary<false>(c, cams + j, width, height, shard, out_primary + j * stride,

@@ -90,8 +90,18 @@ struct rt_inflight {
     unsigned long long last_use = 0;
 };
 
+// Block queues of the persistent-wave launches (rt_params.persistent_waves): one counter per stream that has launched
+// one, each in a 128-byte line of its own, zeroed on that stream ahead of every launch.
+struct rt_queues {
+    rt::DevBuf counters;
+    hipStream_t streams[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int used = 0;
+    uint32_t resident_wgs = 0;  // 256-thread workgroups of the queue kernel the device holds at once
+};
+
 struct rt_ctx {
     int device = 0;
+    rt_queues queues;
     std::vector<rt_inflight> inflight;
     std::vector<rt_cull*> culls;
     rt_cull* last_cull = nullptr;  // the mask of the most recent launch that had one (null: it had none)

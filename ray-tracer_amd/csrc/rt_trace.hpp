@@ -846,6 +846,131 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_tr
     trace_primary_block<WGSL, SHADOW, 0, false, false, false, true, true>(s, fs.f[blockIdx.y], m, out_p, out_s, nullptr);
 }
 
+// Persistent waves with a block queue (rt_params.persistent_waves): as many workgroups as the GPU holds at once, each
+// workgroup takes QUEUE_CHUNK consecutive 8x8 pixel blocks (numbered as k_trace_primary_lean's waves: the four blocks of
+// a 16x16 pixel square follow each other, one per wave) from an atomic counter until none is left. Every workgroup
+// reaches the exit test after finitely many blocks, and all its waves take it together, so the grid always drains.
+//
+// The block body sits in a loop here, and what a loop carries costs registers: the compiler hoists everything that
+// does not depend on the pixel out of it - the kernel's arguments, and the per-frame float arithmetic (bounds relative
+// to the camera, aspect ratio, reciprocals: uniform values, but float results live in VECTOR registers) - 91 vector
+// registers and a hundred spilled scalar ones, five waves per SIMD. So nothing is carried: every turn re-reads the
+// kernel's arguments from the kernel-argument segment through a pointer the compiler cannot see through (scalar loads
+// that hit the constant cache), and the body compiles as it does in k_trace_primary_lean plus the loop's own state: 71
+// vector registers, no scratch, seven waves per SIMD.
+struct QueueArgs {  // the kernel's one argument = the kernel-argument segment
+    DevScene s;
+    DevFrame f;
+    ShardMap m;
+    uint2* out_p;
+    uint2* out_s;
+    const uint32_t* cull_mask;  // the frame's block mask, or null
+    uint32_t* queue;            // next chunk; zero when the launch starts, and zero again when its last workgroup has drawn
+    uint32_t n_waves;           // 8x8 blocks of the launch: four per workgroup of the plain grid
+    uint32_t* cull_zero;        // the mask buffer of the next frame on this stream: zeroed by this launch (or null)
+    uint32_t cull_zero_words;
+};
+constexpr uint32_t QUEUE_CHUNK = 16;  // 8x8 blocks a WORKGROUP takes per turn: four 16x16 pixel squares, a quadrant of each per wave
+
+template <class T>
+__device__ inline void load_kernarg(T& out, const __attribute__((address_space(4))) T* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    const __attribute__((address_space(4))) uint32_t* w = (const __attribute__((address_space(4))) uint32_t*)p;
+    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(T) / 4; ++i) o[i] = w[i];
+}
+
+template <bool WGSL, bool SHADOW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_trace_primary_queue(QueueArgs in_kernarg_segment) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) QueueArgs* KernArgs;
+    // One atomic per workgroup and turn (same-address atomics complete at about one per 15 ns on this chip: one per wave
+    // and four blocks made a 1080p frame four times slower than the plain grid). Thread 0 draws, the others read the
+    // ticket from LDS after the barrier; two slots used in turn, so one barrier per turn is enough: the slot a turn
+    // writes was last read before the previous turn's barrier.
+    __shared__ uint32_t ticket[2];
+    {
+        typedef const __attribute__((address_space(4))) QueueArgs* KA;
+        KA ka0 = (KA)__builtin_amdgcn_kernarg_segment_ptr();
+        if (uint32_t* zero = ka0->cull_zero)
+            for (uint32_t k = blockIdx.x * 256u + threadIdx.x, n = ka0->cull_zero_words; k < n; k += gridDim.x * 256u) zero[k] = 0u;
+    }
+    for (uint32_t turn = 0;; ++turn) {
+        KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));  // a pointer the compiler knows nothing about: what is read through it is read now
+        const uint32_t n_waves = ka->n_waves;
+        if (threadIdx.x == 0) ticket[turn & 1u] = atomicAdd(ka->queue, 1u);
+        __syncthreads();
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket[turn & 1u]);
+        const uint32_t n_chunks = (n_waves + QUEUE_CHUNK - 1) / QUEUE_CHUNK;
+        if (c >= n_chunks) {  // the same in every wave of the workgroup
+            // Every workgroup draws exactly one ticket beyond the chunks; the one that draws the last of those leaves the
+            // counter at zero for the next launch on this stream (no other workgroup touches it any more).
+            if (threadIdx.x == 0 && c == n_chunks + gridDim.x - 1u) *ka->queue = 0u;
+            break;
+        }
+        for (uint32_t j = 0; j < QUEUE_CHUNK / 4; ++j) {
+            const uint32_t gw = c * QUEUE_CHUNK + 4u * j + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            if (gw >= n_waves) break;
+            asm volatile("" : "+s"(ka));
+            DevScene s;
+            DevFrame f;
+            ShardMap m;
+            load_kernarg(s, &ka->s);
+            load_kernarg(f, &ka->f);
+            load_kernarg(m, &ka->m);
+            const uint32_t lane = threadIdx.x & 63;
+            const uint32_t w4 = gw & 3, b16 = gw >> 2;
+            const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;  // 16x16 blocks per tile
+            const uint32_t blk_per_tile = blk_x * blk_y;
+            const uint32_t lt = b16 / blk_per_tile, blk = b16 % blk_per_tile;
+            if (lt >= m.n_local) continue;
+            const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
+            const uint32_t lx = sub_x * 8 + (lane & 7), ly = sub_y * 8 + (lane >> 3);
+            const uint32_t tile = shard_tile(m, lt);
+            const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
+            const bool in_tile = lx < m.tile_w && ly < m.tile_h;
+            bool live = in_tile && px < f.width && py < f.height;
+            if (const uint32_t* mask = ka->cull_mask) {  // as in trace_primary_block: a clear bit = 64 miss records
+                const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile % m.tiles_x) * m.tile_w >> 3) + sub_x));
+                const uint32_t by = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tile / m.tiles_x) * m.tile_h >> 3) + sub_y));
+                const uint32_t blocks_x = (f.width + 7u) >> 3, blocks_y = (f.height + 7u) >> 3;
+                if (bx < blocks_x && by < blocks_y) {
+                    const uint32_t word = mask[(size_t)by * ((blocks_x + 31u) >> 5) + (bx >> 5)];
+                    if (((word >> (bx & 31u)) & 1u) == 0u) live = false;
+                }
+            }
+            uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
+            if (live) {
+                Counters ctr{};
+                const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
+                const V3 d = primary_dir(f, px, py);
+                const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
+                HitRec h;
+                if (trace_ray<WGSL, false, 0, false, false, false>(s, o, rd, h, ctr)) {
+                    ph = make_uint2(h.id, __float_as_uint(h.t));
+                    if (SHADOW) {
+                        const V3 pos = o + d * h.t;
+                        V3 n = hit_normal(s, h, pos);
+                        if (dot(n, d) > 0.0f) n = neg(n);
+                        const V3 so = pos + n * f.shadow_offset;
+                        HitRec oh;
+                        const RayDir to_light = late_shadow_dir((uint32_t)offsetof(QueueArgs, f));
+                        if (trace_ray<WGSL, true, 0, false, false, false>(s, so, to_light, oh, ctr)) sh = make_uint2(oh.id, __float_as_uint(oh.t));
+                    }
+                }
+            }
+            if (in_tile) {
+                const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
+                ka->out_p[oi] = ph;
+                if (SHADOW) ka->out_s[oi] = sh;
+            }
+        }
+    }
+#endif
+}
+
 // trace_ray for waves whose rays sit in DIFFERENT cells with lists of different lengths (rt_params.repack_candidates):
 // (ray, candidate) pairs are dealt out again to the lanes of the wave at DDA steps where that keeps more lanes busy. All 64
 // lanes run one wave-uniform loop, whether their own ray is still alive or not. Per step: a prefix sum of the alive

@@ -33,7 +33,8 @@ struct VarCfg {
     static constexpr int min_waves = (VARIANT >= 20 && VARIANT < 30) ? 8 : 1;
 };
 
-__device__ uint32_t g_queue;         // next block of the persistent variants (zeroed before every launch)
+__device__ uint32_t g_queue[8 * 32];  // next block of the persistent variants: one counter (in a 128-byte line of its own) per stream that
+                                     // launches them, zeroed before every launch
 __device__ uint32_t g_order[65536];  // block handed out at each queue position (variants 5x)
 
 template <int VARIANT>
@@ -60,12 +61,12 @@ __global__ __launch_bounds__(VarCfg<VARIANT>::threads, VarCfg<VARIANT>::min_wave
 // with cheap ones.
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_trace_primary_persist(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
-                                                               uint2* __restrict__ out_s, uint32_t n_waves) {
+                                                               uint2* __restrict__ out_s, uint32_t n_waves, uint32_t* __restrict__ queue) {
     constexpr uint32_t CHUNK = (VARIANT % 10) ? (VARIANT % 10) : 8;
     const uint32_t n_chunks = (n_waves + CHUNK - 1) / CHUNK;
     for (;;) {
         uint32_t c = 0;
-        if ((threadIdx.x & 63) == 0) c = atomicAdd(&g_queue, 1u);
+        if ((threadIdx.x & 63) == 0) c = atomicAdd(queue, 1u);
         c = __builtin_amdgcn_readfirstlane(c);
         if (c >= n_chunks) break;
         for (uint32_t j = 0; j < CHUNK; ++j) {

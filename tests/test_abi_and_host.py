@@ -46,7 +46,27 @@ def test_wire_struct_sizes(rt):
     # sizes asserted in include/rt_types.h (reference src/types.rs, src/grid.rs)
     assert C.sizeof(rt.CameraUniform) == 80 and C.sizeof(rt.GridMetadata) == 96 and C.sizeof(rt.RayDebugInfo) == 80
     assert rt.BOX_DTYPE.itemsize == 96 and rt.TRIANGLE_DTYPE.itemsize == 80 and rt.HIT_DTYPE.itemsize == 8
-    assert C.sizeof(rt.RtStats) == 88 and C.sizeof(rt.RtShard) == 24 and C.sizeof(rt.RtParams) == 64
+    assert C.sizeof(rt.RtStats) == 88 and C.sizeof(rt.RtShard) == 24 and C.sizeof(rt.RtParams) == 68
+
+
+def test_size_table_of_the_header_matches_every_binding(rt):
+    """RT_SIZEOF_* at the end of rt_mi355.h is what bindings in other languages assert (ffi/src/lib.rs cannot be compiled
+    here): the C and C++ compilers check it against the header's structs (test_headers_compile_as_c_and_cpp), this test
+    checks the ctypes views and the Rust source's const asserts against the same numbers."""
+    from ray_tracer_amd import _lib
+    table = {k: int(v) for k, v in re.findall(r"#define RT_SIZEOF_([A-Z_]+) (\d+)", open(HDR).read())}
+    views = {"PARAMS": rt.RtParams, "SHARD": rt.RtShard, "STATS": rt.RtStats, "RENDER_OPTS": _lib.RtRenderOpts, "TEXTURE": _lib.RtTexture,
+             "BVH_STATS": _lib.RtBvhStats}
+    assert set(views) | {"HIT"} == set(table)
+    for name, view in views.items():
+        assert C.sizeof(view) == table[name], name
+    assert rt.HIT_DTYPE.itemsize == table["HIT"]
+    rust = open(os.path.join(ROOT, "ffi", "src", "lib.rs")).read()
+    asserted = {k: int(v) for k, v in re.findall(r"size_of::<Rt(\w+)>\(\) == (\d+)", rust)}
+    assert asserted == {"Params": table["PARAMS"], "Shard": table["SHARD"], "Hit": table["HIT"]}
+    fields = re.search(r"pub struct RtParams \{(.*?)\n\}", rust, re.S).group(1)
+    n_words = sum(3 if "[f32; 3]" in f else 1 for f in fields.split(",") if ":" in f)
+    assert 4 * n_words == table["PARAMS"], "ffi/src/lib.rs RtParams has a different number of fields"
 
 
 def test_oracle_binding_shares_the_header_structs(rt, ob):

@@ -73,10 +73,12 @@ if any(v >= 50 for v in variants):
     L.rt_dbg_set_order(core._h, order.ctypes.data_as(C.c_void_p), C.c_size_t(nw))
     print(f"order from {nw} wave times: longest {dur.max() / 100:.1f} us, mean {dur.mean() / 100:.2f} us")
 times = {v: [] for v in variants}
-TWO = os.environ.get("RT_TWO") == "1"  # two frames in flight on two streams, as bench.py runs them
+# RT_FLIGHT=n: n frames in flight on n streams, as bench.py runs them (RT_TWO=1: two, the older spelling)
+FLIGHT = int(os.environ.get("RT_FLIGHT", "2" if os.environ.get("RT_TWO") == "1" else "1"))
+TWO = FLIGHT > 1
 if TWO:
-    streams = [torch.cuda.Stream() for _ in range(2)]
-    bufs = [(torch.empty_like(p), torch.empty_like(p)) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(FLIGHT)]
+    bufs = [(torch.empty_like(p), torch.empty_like(p)) for _ in range(FLIGHT)]
 
 
 def frames(n):
@@ -85,8 +87,8 @@ def frames(n):
             core.trace_primary(cam, W, H, out_primary=p, out_shadow=s)
         return
     for k in range(n):
-        core.set_stream(streams[k % 2].cuda_stream)
-        core.trace_primary(cam, W, H, out_primary=bufs[k % 2][0], out_shadow=bufs[k % 2][1])
+        core.set_stream(streams[k % FLIGHT].cuda_stream)
+        core.trace_primary(cam, W, H, out_primary=bufs[k % FLIGHT][0], out_shadow=bufs[k % FLIGHT][1])
 
 
 for v in variants:

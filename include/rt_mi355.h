@@ -98,9 +98,11 @@ typedef struct rt_params {
                                          and mark the 8x8 pixel blocks they can be seen through; a block left unmarked
                                          has rays that meet no candidate list, so its 64 records are written as misses
                                          without a traversal. The same answers bit for bit.
-                                         0: never. 1 (default): where the extra launch is hidden - while frames of this
-                                         context are still running on two or more other streams (three frames in flight),
-                                         or for four or more frames in one rt_render_frames call; a lone frame on an
+                                         0: never. 1 (default): where the extra launch is hidden - once two or more OTHER
+                                         streams of this context have been given a frame since the last rt_sync (three
+                                         frames in flight; decided from the call sequence alone, so every run of the same
+                                         calls launches the same kernels), or for four or more frames in one
+                                         rt_render_frames / rt_trace_primary_frames call; a lone frame on an
                                          idle GPU waits for its longest waves either way and would only start later,
                                          and with two frames in flight the launch costs what the mask saves. 2: always.
                                          Applies when tiles are multiples of 8 pixels, the grid has at most 2^21 cells, the
@@ -298,9 +300,11 @@ int rt_trace_primary_frames(rt_ctx* ctx, const CameraUniform* cameras, uint32_t 
  *   - params.collect_stats must be 0                                                                 RT_ERR_STATE
  *   - a shard with an owner table only if an allocating call has used that table before             RT_ERR_STATE
  * Every call on a GPU shares that GPU's array, whichever context it comes from: calls on one context are ordered
- * as rt_set_stream describes, calls from DIFFERENT contexts that overlap on one GPU race when their scenes have
- * boxes. The array keeps the last call's records; every call rewrites all records it reads, so nothing needs
- * clearing between calls. */
+ * as rt_set_stream describes; a call from ANOTHER context whose scene has boxes is ordered on the GPU behind the
+ * launches of the context that used the array last (its stream waits for an event that context recorded; events are
+ * made in rt_create, nothing is allocated here), so contexts can share a GPU, taking turns at the array - calls made
+ * at the same time from different host threads are served one after the other. The array keeps the last call's
+ * records; every call rewrites all records it reads, so nothing needs clearing between calls. */
 #define RT_NOALLOC_MAX_BOXES 8192u
 int rt_trace_primary_noalloc(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height,
                              const rt_shard* shard, rt_hit* out_primary, rt_hit* out_shadow);

@@ -32,6 +32,15 @@ static __device__ __align__(256) float4 scratch[4 * NOALLOC_MAX_BOXES];
 constexpr int NOALLOC_MAX_DEVICES = 64;
 float4* g_scratch_ptr[NOALLOC_MAX_DEVICES];  // written under g_scratch_lock, read after rt_create returned
 std::mutex g_scratch_lock;
+// Every context on a GPU shares that GPU's array. Inside one context the stream switch orders its users (scratch_busy /
+// ev_order in rt_set_stream); between contexts this does: the context whose launches used the array last, and the event
+// it recorded behind them (its own, made in rt_create). A call from ANOTHER context makes its stream wait for that event
+// before its k_box_frame overwrites the records, then takes the entry over. Nothing here allocates.
+struct ScratchUser {
+    rt_ctx* ctx = nullptr;
+    hipEvent_t done = nullptr;
+};
+ScratchUser g_scratch_user[NOALLOC_MAX_DEVICES];  // under g_scratch_lock
 
 hipError_t scratch_for_device(int device) {  // the device must be current
     if (device < 0 || device >= NOALLOC_MAX_DEVICES) return hipSuccess;  // rt_trace_primary_noalloc reports it
@@ -264,6 +273,7 @@ int scene_barrier(rt_ctx* c) {
         RT_HIP(c, hipDeviceSynchronize());
         c->other_streams_busy = false;
         c->scratch_busy = false;
+        c->traced_on.clear();
     }
     return RT_OK;
 }
@@ -518,35 +528,29 @@ static bool invert_columns(const double c0[3], const double c1[3], const double 
     return true;
 }
 
-// On how many of the context's OTHER streams a traced frame may still be running (a frame on the current stream does
-// not overlap the one being queued behind it).
-static uint32_t frames_in_flight(rt_ctx* c) {
+// How many OTHER streams of the context have been given a trace since the last rt_sync (or scene change): the frames
+// the one being queued can overlap. Host state only - the same call sequence takes the same decisions on every run.
+static uint32_t other_streams_tracing(const rt_ctx* c) {
     uint32_t n = 0;
-    for (const rt_inflight& e : c->inflight)
-        if (e.stream != c->stream && hipEventQuery(e.done) == hipErrorNotReady) ++n;
-    (void)hipGetLastError();
+    for (hipStream_t s : c->traced_on)
+        if (s != c->stream) ++n;
     return n;
 }
 
-// After a trace launch on the context's stream: the event that frames_in_flight() asks.
-static int mark_in_flight(rt_ctx* c) {
-    rt_inflight* hit = nullptr;
-    for (rt_inflight& e : c->inflight)
-        if (e.stream == c->stream) hit = &e;
-    if (!hit) {
-        if (c->inflight.size() < CULL_MAX_SLOTS) {
-            rt_inflight fresh;
-            RT_HIP(c, hipEventCreateWithFlags(&fresh.done, hipEventDisableTiming));
-            c->inflight.push_back(fresh);
-            hit = &c->inflight.back();
-        } else {
-            for (rt_inflight& e : c->inflight)
-                if (!hit || e.last_use < hit->last_use) hit = &e;
+// After the host has waited for everything queued on `s`: no frame is in flight there any more.
+static void stream_drained(rt_ctx* c, hipStream_t s) {
+    for (size_t k = 0; k < c->traced_on.size(); ++k)
+        if (c->traced_on[k] == s) {
+            c->traced_on.erase(c->traced_on.begin() + (long)k);
+            return;
         }
-        hit->stream = c->stream;
-    }
-    hit->last_use = ++c->plan_clock;
-    RT_HIP(c, hipEventRecord(hit->done, c->stream));
+}
+
+// After a trace launch on the context's stream.
+static int mark_in_flight(rt_ctx* c) {
+    for (hipStream_t s : c->traced_on)
+        if (s == c->stream) return RT_OK;
+    if (c->traced_on.size() < 64) c->traced_on.push_back(c->stream);
     return RT_OK;
 }
 
@@ -626,11 +630,11 @@ int cull_masks_for(rt_ctx* c, const DevScene& s, const DevFrame* fs, uint32_t n,
     *mask = nullptr;
     if (!c->params.cull_empty_blocks || s.nb != 0 || n == 0 || n > CULL_MAX_FRAMES) return RT_OK;
     // 1: only where it pays. The mask is one more launch the trace has to wait for, 9 us alone and 20-30 us beside other
-    // streams' work. A group of frames in one launch shares that wait; with frames running on two or more other streams
+    // streams' work. A group of frames in one launch shares that wait; with frames given to two or more other streams
     // it is hidden and the traversals saved are time gained (three in flight: 67 -> 62 us per frame); with one other
     // stream it is break-even for hit records and a loss for the shaded picture, and a frame traced on an idle GPU
     // waits for its few longest waves whatever the others do, and would only start later.
-    if (c->params.cull_empty_blocks == 1 && !always && n < 4 && frames_in_flight(c) < 2) return RT_OK;
+    if (c->params.cull_empty_blocks == 1 && !always && n < 4 && other_streams_tracing(c) < 2) return RT_OK;
     CullFrames cfs;
     for (uint32_t j = 0; j < n; ++j)
         if (!cull_frame(s, fs[j], m, &cfs.f[j])) return RT_OK;
@@ -1021,7 +1025,8 @@ extern "C" int rt_create(rt_ctx** out, int device_id, const rt_params* params) {
     memset(&c->last_stats, 0, sizeof(c->last_stats));
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming)) != hipSuccess) {
         g_create_error = std::string("rt_create: stream/event creation: ") + hipGetErrorString(e);
         delete c;
         return RT_ERR_NO_DEVICE;
@@ -1052,8 +1057,6 @@ extern "C" void rt_destroy(rt_ctx* c) {
         for (DevBuf& b : p->buf) b.release();
         delete p;
     }
-    for (rt_inflight& e : c->inflight)
-        if (e.done) (void)hipEventDestroy(e.done);
     for (rt_cull* k : c->culls) {
         k->buf[0].release();
         k->buf[1].release();
@@ -1062,6 +1065,13 @@ extern "C" void rt_destroy(rt_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_order) (void)hipEventDestroy(c->ev_order);
+    if (c->ev_scratch) {
+        {  // this context's launches are done (synchronised above): nobody has to wait for its event any more
+            std::lock_guard<std::mutex> hold(g_scratch_lock);
+            if (c->device >= 0 && c->device < NOALLOC_MAX_DEVICES && g_scratch_user[c->device].ctx == c) g_scratch_user[c->device] = ScratchUser{};
+        }
+        (void)hipEventDestroy(c->ev_scratch);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1097,6 +1107,7 @@ extern "C" int rt_sync(rt_ctx* c) {
     } else {
         RT_HIP(c, hipStreamSynchronize(c->stream));
     }
+    c->traced_on.clear();  // nothing is in flight any more: the next frame is a lone one until others join it
     c->scratch_busy = false;
     return RT_OK;
 }
@@ -1269,6 +1280,7 @@ extern "C" int rt_get_cull_stats(rt_ctx* c, uint32_t* blocks_total, uint32_t* bl
     std::vector<uint32_t> host(k->words);
     RT_HIP(c, hipMemcpyAsync(host.data(), k->buf[k->cur].p, (size_t)k->words * sizeof(uint32_t), hipMemcpyDeviceToHost, k->stream));
     RT_HIP(c, hipStreamSynchronize(k->stream));
+    stream_drained(c, k->stream);
     uint32_t kept = 0;
     for (uint32_t w : host) kept += (uint32_t)__builtin_popcount(w);
     if (blocks_total) *blocks_total = k->blocks;
@@ -1397,8 +1409,12 @@ static int trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t width, ui
         RT_HIP(c, c->out_s.reserve(n_out * sizeof(uint2)));
         os = c->out_s.as<uint2>();
     }
+    std::unique_lock<std::mutex> scratch_hold(g_scratch_lock, std::defer_lock);
     if (NOALLOC) {
         if (c->grid_nb) {  // every record of boxes 0 .. nb-1 is rewritten: nothing in the array has to start at zero
+            scratch_hold.lock();  // until this call's launches are queued and its event recorded (end of the function)
+            ScratchUser& last = g_scratch_user[c->device];
+            if (last.ctx && last.ctx != c) RT_HIP(c, hipStreamWaitEvent(c->stream, last.done, 0));
             const float t_lerp = (sinf(cam->time * 2.0f) + 1.0f) * 0.5f;  // raytracer_unified.wgsl:201,449
             hipLaunchKernelGGL(k_box_frame, dim3((c->nb + 255) / 256), dim3(256), 0, c->stream, c->boxes.as<BoxData>(), c->nb,
                                t_lerp, ld3(cam->position), cam->lod_factor, cam->min_pixel_size, c->params.lod_cull, static_boxes);
@@ -1426,12 +1442,18 @@ static int trace_primary(rt_ctx* c, const CameraUniform* cam, uint32_t width, ui
                   : launch_primary<false, false>(c, stats, grid, s, f, m, op, os, !NOALLOC);
     if (lr) return lr;
     RT_HIP(c, hipGetLastError());
+    if (NOALLOC && c->grid_nb) {  // behind the launches that read the static array: what another context's call waits for
+        RT_HIP(c, hipEventRecord(c->ev_scratch, c->stream));
+        g_scratch_user[c->device] = ScratchUser{c, c->ev_scratch};
+    }
     if (host_p) RT_HIP(c, hipMemcpyAsync(out_primary, op, n_out * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
     if (host_s) RT_HIP(c, hipMemcpyAsync(out_shadow, os, n_out * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
     if (stats) {
         if (int r = fetch_stats(c)) return r;
+        stream_drained(c, c->stream);
     } else if (host_p || host_s) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
+        stream_drained(c, c->stream);
     }
     return RT_OK;
 }
@@ -1890,8 +1912,10 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
     if (host_out) RT_HIP(c, hipMemcpyAsync(out_rgba8, out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     if (stats) {
         if (int r = fetch_stats(c)) return r;
+        stream_drained(c, c->stream);
     } else if (host_out) {
         RT_HIP(c, hipStreamSynchronize(c->stream));
+        stream_drained(c, c->stream);
     }
     return RT_OK;
 }

@@ -83,13 +83,6 @@ struct rt_cull {
     unsigned long long last_use = 0;
 };
 
-// "Is a frame of this context still running?": one event per stream that has traced (recorded after the launch).
-struct rt_inflight {
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
-    unsigned long long last_use = 0;
-};
-
 // Block queues of the persistent-wave launches (rt_params.persistent_waves): one counter per stream that has launched
 // one, each in a 128-byte line of its own, zeroed on that stream ahead of every launch.
 struct rt_queues {
@@ -102,7 +95,7 @@ struct rt_queues {
 struct rt_ctx {
     int device = 0;
     rt_queues queues;
-    std::vector<rt_inflight> inflight;
+    std::vector<hipStream_t> traced_on;  // streams given a trace since the last rt_sync: what params.cull_empty_blocks = 1 decides by
     std::vector<rt_cull*> culls;
     rt_cull* last_cull = nullptr;  // the mask of the most recent launch that had one (null: it had none)
     std::vector<rt_plan*> plans;
@@ -180,6 +173,7 @@ struct rt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // Frames in flight on several streams (rt_set_stream): see the rules at rt_set_stream in rt_api.hip.
     hipEvent_t ev_order = nullptr;
+    hipEvent_t ev_scratch = nullptr;  // recorded behind launches that use the GPU's static scratch array (rt_trace_primary_noalloc)
     // multi-GPU (rt_comm_init): an ncclComm_t, kept untyped so that only rt_comm.hip needs RCCL's header
     void* comm = nullptr;
     int comm_rank = 0, comm_size = 0;

@@ -709,6 +709,14 @@ __device__ inline RayDir late_shadow_dir(uint32_t frame_byte_offset) {
 #endif
 }
 static_assert(sizeof(RayDir) == 60 && offsetof(RayDir, sx) == 36 && offsetof(RayDir, dix) == 48, "late_shadow_dir reads RayDir word by word");
+// Kernels that read arguments late (k_trace_primary_lean, k_trace_primary_frames, k_trace_primary_planned,
+// k_trace_primary_queue) take (DevScene, DevFrame or DevFrames, ...) as their first arguments; the kernel-argument
+// segment lays arguments out in order, each at its natural alignment, which is what offsetof() of the *Args structs
+// (same members, same order) evaluates to. Reordering or inserting an argument in one of those kernels means changing
+// its struct too.
+static_assert(offsetof(PrimaryArgs, s) == 0 && offsetof(PrimaryArgs, f) == (sizeof(DevScene) + alignof(DevFrame) - 1) / alignof(DevFrame) * alignof(DevFrame) &&
+                  offsetof(PrimaryFramesArgs, fs) == offsetof(PrimaryArgs, f),
+              "late argument reads assume the scene first, the frame(s) right behind it");
 
 #ifdef RT_EXPERIMENTS
 __device__ unsigned long long g_wave_t[2 * 65536];  // development builds: s_memrealtime (100 MHz) at wave start / end,
@@ -782,7 +790,8 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
                 HitRec oh;
                 n_rays++;
                 n_sr++;
-                const RayDir to_light = late_shadow_dir(a_frame);
+                // LATE: the kernel's leading arguments are PrimaryArgs' (checked where the kernels are declared)
+                const RayDir to_light = LATE ? late_shadow_dir(a_frame) : f.shadow;
                 if (trace_ray<WGSL, true, STATS, BOXES, TEX, WIDE>(s, so, to_light, oh, ctr)) {
                     n_sh++;
                     sh = make_uint2(oh.id, __float_as_uint(oh.t));
@@ -1344,6 +1353,7 @@ __device__ inline void steer_plan(const BlockPlan& p, const PlanReader& plan) { 
 // once), then the plain kernel's 16x16-pixel workgroups. One traversal body serves both shapes (the lanes-per-ray count
 // is a run-time scalar): two bodies in one kernel need 76 vector registers, two kernels need two streams per frame in
 // flight, and the four hardware queues of a process are then shared between them and frames no longer overlap.
+// The first two arguments are read again late (late_shadow_dir at offsetof(PrimaryArgs, f)): keep (DevScene, DevFrame) first.
 template <bool WGSL, bool SHADOW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_trace_primary_planned(
     DevScene s, DevFrame f, ShardMap m, BlockPlan p, uint2* __restrict__ out_p, uint2* __restrict__ out_s) {

@@ -178,17 +178,25 @@ def test_default_mode_masks_only_with_three_frames_in_flight_or_frame_groups(rt,
             core.set_stream(streams[k % 2].cuda_stream)
             core.trace_primary(cam, w, h, out_primary=outs[k % 2][0], out_shadow=outs[k % 2][1])
         assert core.cull_stats() == (0, 0)
-        torch.cuda.synchronize()
-        # three in flight: a frame that finds the two other streams busy gets a mask
+        core.sync()
+        # three in flight: a frame queued after frames on two other streams (since the last rt_sync) gets a mask
         for k in range(36):
             core.set_stream(streams[k % 3].cuda_stream)
             core.trace_primary(cam, w, h, out_primary=outs[k % 3][0], out_shadow=outs[k % 3][1])
         masked = core.cull_stats()  # of the last launch; waits for its stream
-        torch.cuda.synchronize()
+        core.sync()  # rt_sync: nothing is in flight any more, the next frame is a lone one again
         assert masked[0] == -(-w // 8) * -(-h // 8) and 0 < masked[1] < masked[0], masked
         for op, os_ in outs:
             assert_hits_equal(op.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want_p, "frames in flight: primary")
             assert_hits_equal(os_.cpu().numpy().view(rt.HIT_DTYPE).reshape(-1), want_s, "frames in flight: shadow")
+        # the decision follows the call sequence alone: the same three-stream sequence again takes the same decisions
+        for k in range(3):
+            core.set_stream(streams[k].cuda_stream)
+            core.trace_primary(cam, w, h, out_primary=outs[k][0], out_shadow=outs[k][1])
+            assert (core.cull_stats() != (0, 0)) == (k == 2), k
+            if k < 2:  # cull_stats waited for that stream: queue its frame again so that it counts as in flight
+                core.trace_primary(cam, w, h, out_primary=outs[k][0], out_shadow=outs[k][1])
+        core.sync()
         # a group of frames in one launch shares the mask launch: masks even on an idle GPU; fewer than four frames: none
         core.set_stream(streams[0].cuda_stream)
         cams = [rt.Camera((2500 - 100 * k, 900, 2600), 3.9, -0.25).to_uniform(0.0, float(h)) for k in range(4)]

@@ -135,3 +135,38 @@ def test_noalloc_limits_are_errors(rt, ob):
         assert e.value.code == rt.RT_ERR_LIMIT and "8192" in str(e.value)
     finally:
         core.close()
+
+
+def test_two_contexts_take_turns_at_the_static_array(rt, ob):
+    """Two contexts on one GPU, different box scenes, rt_trace_primary_noalloc calls queued alternately on two streams
+    without any host synchronisation in between: each context's records must equal its own allocating call's. Both
+    share the GPU's one static array of per-frame box records; the library orders them by events."""
+    import torch
+    cores, want, cams, outs = [], [], [], []
+    w, h = 256, 144
+    try:
+        for k, (n, seed) in enumerate(((300, 31), (90, 32))):
+            c = rt.TraceCore(0)
+            c.set_scene(_boxes(ob, n, seed, 3), ob.generate_test_triangles(800 + 400 * k))
+            c.build_grid(cell_size=8.0)
+            cam = rt.Camera((10 - 30 * k, 30, 140), math.pi + 0.1 * k, -0.2).to_uniform(0.7 + k, float(h))
+            p, s = c.trace_primary(cam, w, h)
+            cores.append(c), cams.append(cam), want.append((p.view(np.uint32).reshape(-1, 2), s.view(np.uint32).reshape(-1, 2)))
+            outs.append([(torch.zeros((w * h, 2), dtype=torch.int32, device="cuda"), torch.zeros((w * h, 2), dtype=torch.int32, device="cuda"))
+                         for _ in range(6)])
+        assert not np.array_equal(want[0][0], want[1][0])
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for k, c in enumerate(cores):
+            c.set_stream(streams[k].cuda_stream)
+        for rnd in range(6):  # A, B, A, B, ... each call overwrites the array the other's kernels were given
+            for k, c in enumerate(cores):
+                c.trace_primary_noalloc(cams[k], w, h, outs[k][rnd][0], outs[k][rnd][1])
+        for c in cores:
+            c.sync()
+        for k in range(2):
+            for rnd in range(6):
+                p, s = (b.cpu().numpy().view(np.uint32) for b in outs[k][rnd])
+                assert np.array_equal(p, want[k][0]) and np.array_equal(s, want[k][1]), f"context {k}, call {rnd}"
+    finally:
+        for c in cores:
+            c.close()

@@ -136,8 +136,8 @@ typedef struct rt_params {
  * tile_w x tile_h tiles numbered row-major, and the tiles into rounds of `stride`
  * consecutive tiles. With owner == NULL the call traces tile `first` of every round
  * (tiles first, first+stride, first+2*stride, ...). With an owner table - `stride`
- * entries of host memory, owner[o] = the rank that traces tile o of every round - it
- * traces the tiles whose owner is `first`, so ranks can own unequal shares of the
+ * entries of host memory (at most 65 536), owner[o] = the rank that traces tile o of every round, or RT_OWNER_SKY for
+ * a tile nobody traces (rt_tile_flags) - it traces the tiles whose owner is `first`, so ranks can own unequal shares of the
  * frame, spread over it as finely as the table says: a rank that also gathers and
  * assembles can be given less to trace (rt_assemble_frames takes the same table).
  * Either way the tiles are packed in increasing tile order: local tile j occupies
@@ -485,6 +485,27 @@ int rt_assemble_frames_rgb8(rt_ctx* ctx, const uint8_t* gathered, uint32_t width
 int rt_assemble_frames(rt_ctx* ctx, const uint8_t* gathered, uint32_t pixel_format, uint32_t width, uint32_t height,
                        uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, const uint32_t* owner, uint32_t round,
                        uint32_t n_frames, size_t rank_stride, size_t frame_stride, uint8_t* images);
+
+/* Tiles of a frame that show nothing but sky: flags[t] = 0 when no 8x8 pixel block of tile t (row-major, tile_w x tile_h
+ * pixels, both multiples of 8) can meet geometry from this camera - the block mask of params.cull_empty_blocks, made for
+ * the whole frame whatever the parameter says - and 1 otherwise; all 1 when the frame can have no mask (boxes, a grid
+ * or frame too large, a camera the bound on the float DDA's drift does not cover). A sky tile is a function of the camera
+ * alone, so in a multi-GPU run nobody has to render or send it: the ranks deal the other tiles among themselves with
+ * an owner table whose sky entries are RT_OWNER_SKY, and the gathering rank's rt_assemble_frames_sky fills those from the
+ * camera. Synchronous (one small launch and a read-back): for cameras known ahead of the frames. flags: host memory, one
+ * byte per tile. No reference counterpart. */
+#define RT_OWNER_SKY 0xFFFFFFFFu
+int rt_tile_flags(rt_ctx* ctx, const CameraUniform* camera, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
+                  uint8_t* flags);
+
+/* rt_assemble_frames for owner tables with RT_OWNER_SKY entries: those tiles are not read from `gathered` but written as
+ * the shader's sky (src/raytracer_unified.wgsl:591-596) seen through cameras[j] for frame j - byte for byte what
+ * rt_render_frames writes for a pixel whose ray meets nothing (no debug-pixel highlight: callers that use one render
+ * every tile). cameras: host memory, n_frames entries, n_frames <= 64. No reference counterpart. */
+int rt_assemble_frames_sky(rt_ctx* ctx, const uint8_t* gathered, uint32_t pixel_format, uint32_t width, uint32_t height,
+                           uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, const uint32_t* owner, uint32_t round,
+                           const CameraUniform* cameras, uint32_t n_frames, size_t rank_stride, size_t frame_stride,
+                           uint8_t* images);
 
 /* Counters of the most recent call made with params.collect_stats = 1. rt_trace_primary and rt_trace_rays fill
  * every field (their counting kernels walk the reference's full lists). rt_render / rt_render_frames fill rays,

@@ -29,6 +29,7 @@ assert TRIANGLE_DTYPE.itemsize == 80 and BOX_DTYPE.itemsize == 96 and HIT_DTYPE.
 assert MATERIAL_DTYPE.itemsize == 64
 
 RT_MISS = 0xFFFFFFFF
+RT_OWNER_SKY = 0xFFFFFFFF  # rt_shard.owner entry of a tile nobody traces (rt_tile_flags, rt_assemble_frames_sky)
 RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_STATE, RT_ERR_LIMIT, RT_ERR_COMM = 0, -1, -2, -3, -4, -5, -6
 RT_COMM_ID_BYTES = 128
 RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES = 0, 1
@@ -149,6 +150,8 @@ PROTOTYPES = {
     "rt_assemble_frames_rgba8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, C.c_size_t, C.c_size_t, _VP]),
     "rt_assemble_frames_rgb8": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, C.c_size_t, C.c_size_t, _VP]),
     "rt_assemble_frames": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, _VP, _U32, _U32, C.c_size_t, C.c_size_t, _VP]),
+    "rt_assemble_frames_sky": (_I, [_VP, _VP, _U32, _U32, _U32, _U32, _U32, _U32, _VP, _U32, _VP, _U32, C.c_size_t, C.c_size_t, _VP]),
+    "rt_tile_flags": (_I, [_VP, C.POINTER(CameraUniform), _U32, _U32, _U32, _U32, _VP]),
     "rt_render_frames": (_I, [_VP, _VP, _U32, _U32, _U32, C.POINTER(RtShard), C.POINTER(RtRenderOpts), _VP]),
     "rt_default_render_opts": (None, [C.POINTER(RtRenderOpts)]),
     "rt_set_materials": (_I, [_VP, _VP, _U32]),

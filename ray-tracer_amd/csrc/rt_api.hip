@@ -193,6 +193,28 @@ struct AssemblePlan {
     uint32_t n_ranks, round;
     const uint32_t* places;
 };
+constexpr uint32_t OWNER_SKY = 0xFFFFFFFFu;  // RT_OWNER_SKY: a tile nobody rendered; the assemble kernels fill it from the camera
+
+// What the sky fill needs of a frame's camera (primary_dir reads nothing else), for up to 64 frames of a group.
+constexpr uint32_t SKY_MAX_FRAMES = 64;
+struct SkyFrames {
+    float basis[SKY_MAX_FRAMES][9];  // fwd, right, up
+    float fov_scale;
+    uint32_t enabled;
+};
+
+// The shader's sky colour for pixel (px, py) of frame j as k_render writes it for a ray that meets nothing
+// (rt_render.hpp: acc = 0 + mix(...) * 1, then the 8-bit store); alpha 255.
+__device__ inline uint32_t sky_pixel(const SkyFrames& sky, uint32_t j, uint32_t width, uint32_t height, uint32_t px, uint32_t py) {
+    DevFrame f;
+    for (int k = 0; k < 3; ++k) f.fwd[k] = sky.basis[j][k], f.right[k] = sky.basis[j][3 + k], f.up[k] = sky.basis[j][6 + k];
+    f.fov_scale = sky.fov_scale;
+    f.width = width, f.height = height;
+    const V3 d = primary_dir(f, px, py);
+    const float t = (d.y + 1.0f) * 0.5f;
+    const V3 acc = v3(0.0f, 0.0f, 0.0f) + mix(v3(0.3f, 0.5f, 0.7f), v3(0.5f, 0.7f, 1.0f), t) * 1.0f;
+    return unorm8(acc.x) | (unorm8(acc.y) << 8) | (unorm8(acc.z) << 16) | 0xFF000000u;
+}
 __device__ inline void locate_tile(const AssemblePlan& p, uint32_t tile, uint32_t& rank, uint32_t& lt) {
     if (!p.places) {
         rank = tile % p.n_ranks;
@@ -207,11 +229,17 @@ __device__ inline void locate_tile(const AssemblePlan& p, uint32_t tile, uint32_
 // One pixel per thread; RGB8: 3-byte pixels in, 4-byte pixels (alpha 255) out.
 template <class PIXEL, bool RGB8>
 __global__ void k_assemble(const void* __restrict__ gathered, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
-                           uint32_t tiles_x, AssemblePlan plan, size_t per_rank, size_t frame_stride, PIXEL* __restrict__ image) {
+                           uint32_t tiles_x, AssemblePlan plan, size_t per_rank, size_t frame_stride, PIXEL* __restrict__ image, SkyFrames sky) {
     uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= width || y >= height) return;
     uint32_t rank, lt;
     locate_tile(plan, (y / tile_h) * tiles_x + (x / tile_w), rank, lt);
+    if constexpr (sizeof(PIXEL) == 4) {
+        if (sky.enabled && rank == OWNER_SKY) {
+            image[(size_t)blockIdx.z * width * height + (size_t)y * width + x] = sky_pixel(sky, blockIdx.z, width, height, x, y);
+            return;
+        }
+    }
     const size_t src = (size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h +
                        (size_t)(y % tile_h) * tile_w + (x % tile_w);
     const size_t dst = (size_t)blockIdx.z * width * height + (size_t)y * width + x;
@@ -229,12 +257,25 @@ __global__ void k_assemble(const void* __restrict__ gathered, uint32_t width, ui
 template <uint32_t PER, bool RGB8>
 __global__ __launch_bounds__(256) void k_assemble_x16(const uint32_t* __restrict__ gathered, uint32_t width, uint32_t height,
                                                       uint32_t tile_w, uint32_t tile_h, uint32_t tiles_x, AssemblePlan plan,
-                                                      size_t per_rank, size_t frame_stride, uint4* __restrict__ image) {
+                                                      size_t per_rank, size_t frame_stride, uint4* __restrict__ image, SkyFrames sky) {
     uint32_t rank, lt;
     locate_tile(plan, blockIdx.y * tiles_x + blockIdx.x, rank, lt);
     const uint32_t x0 = blockIdx.x * tile_w, y0 = blockIdx.y * tile_h;
     const uint32_t vec_x = tile_w / PER;
     const uint32_t cols = min(vec_x, (width - x0) / PER), rows = min(tile_h, height - y0);
+    if constexpr (PER == 4) {  // 4-byte pixels: a tile nobody rendered is the sky seen through this frame's camera
+        if (sky.enabled && rank == OWNER_SKY) {
+            uint4* dst = image + ((size_t)blockIdx.z * width * height + (size_t)y0 * width + x0) / PER;
+            for (uint32_t q = threadIdx.x; q < vec_x * rows; q += blockDim.x) {
+                const uint32_t ly = q / vec_x, lq = q - ly * vec_x;
+                if (lq >= cols) continue;
+                const uint32_t px = x0 + lq * PER, py = y0 + ly;
+                dst[(size_t)ly * (width / PER) + lq] = make_uint4(sky_pixel(sky, blockIdx.z, width, height, px, py), sky_pixel(sky, blockIdx.z, width, height, px + 1, py),
+                                                                 sky_pixel(sky, blockIdx.z, width, height, px + 2, py), sky_pixel(sky, blockIdx.z, width, height, px + 3, py));
+            }
+            return;
+        }
+    }
     // first record of the tile, in vectors; RGB8: a multiple of 4 pixels is a whole number of dwords
     const size_t first = ((size_t)blockIdx.z * frame_stride + (size_t)rank * per_rank + (size_t)lt * tile_w * tile_h) / PER;
     const uint32_t* src = gathered + first * (RGB8 ? 3 : 4);
@@ -357,7 +398,7 @@ int update_box_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n) {
 
 int update_box_frame(rt_ctx* c, const CameraUniform* cam) { return update_box_frames(c, cam, 1); }
 
-constexpr uint32_t MAX_OWNER_TABLE = 4096;
+constexpr uint32_t MAX_OWNER_TABLE = 65536;  // a table over every 32x32 tile of a 7680x4320 frame has 32 400 entries
 
 // Device copy of `content`, uploaded the first time `key` is seen.
 int table_for(rt_ctx* c, std::vector<uint32_t>&& key, const std::vector<uint32_t>& content, const uint32_t** dev,
@@ -1586,8 +1627,19 @@ extern "C" int rt_trace_rays(rt_ctx* c, const CameraUniform* cam, const float* o
 template <class PIXEL, bool RGB8>
 static int assemble_tiles(rt_ctx* c, const void* gathered, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
                           uint32_t n_ranks, const uint32_t* owner, uint32_t round, size_t rank_stride, void* image, const char* who,
-                          uint32_t n_frames = 1, size_t frame_stride = 0) {
+                          uint32_t n_frames = 1, size_t frame_stride = 0, const CameraUniform* sky_cams = nullptr) {
     if (int r = use(c)) return r;
+    SkyFrames sky;
+    memset(&sky, 0, sizeof(sky));
+    if (sky_cams) {  // owner entries of RT_OWNER_SKY are filled from these cameras
+        if (sizeof(PIXEL) != 4 || !owner) return fail(c, RT_ERR_INVALID, "%s: sky tiles need an owner table and 4-byte pixels", who);
+        if (n_frames > SKY_MAX_FRAMES) return fail(c, RT_ERR_LIMIT, "%s: %u frames with sky tiles (max %u)", who, n_frames, SKY_MAX_FRAMES);
+        for (uint32_t j = 0; j < n_frames; ++j)
+            for (int k = 0; k < 3; ++k)
+                sky.basis[j][k] = sky_cams[j].forward[k], sky.basis[j][3 + k] = sky_cams[j].right[k], sky.basis[j][6 + k] = sky_cams[j].up[k];
+        sky.fov_scale = tanf(c->params.fov);  // as make_frame evaluates it
+        sky.enabled = 1;
+    }
     if (!gathered || !image || !width || !height || !tile_w || !tile_h || !n_ranks)
         return fail(c, RT_ERR_INVALID, "%s: NULL or zero argument", who);
     if (!is_device_ptr(gathered) || !is_device_ptr(image))
@@ -1605,13 +1657,18 @@ static int assemble_tiles(rt_ctx* c, const void* gathered, uint32_t width, uint3
         key.insert(key.end(), owner, owner + round);
         const uint32_t rem = n_tiles % round;
         for (uint32_t o = 0; o < round; ++o) {
+            if (sky.enabled && owner[o] == OWNER_SKY) {
+                places[3 * o] = OWNER_SKY;
+                continue;
+            }
             if (owner[o] >= n_ranks) return fail(c, RT_ERR_INVALID, "%s: owner[%u] = %u, but there are %u ranks", who, o, owner[o], n_ranks);
             places[3 * o] = owner[o];
             places[3 * o + 1] = count[owner[o]]++;
             tiles[owner[o]] += o < rem ? 1u : 0u;
         }
         most = 0;
-        for (uint32_t o = 0; o < round; ++o) places[3 * o + 2] = count[owner[o]];
+        for (uint32_t o = 0; o < round; ++o)
+            if (places[3 * o] != OWNER_SKY) places[3 * o + 2] = count[owner[o]];
         for (uint32_t r = 0; r < n_ranks; ++r) most = std::max(most, n_tiles / round * count[r] + tiles[r]);
         plan.round = round;
         if (int r = table_for(c, std::move(key), places, &plan.places)) return r;
@@ -1633,10 +1690,10 @@ static int assemble_tiles(rt_ctx* c, const void* gathered, uint32_t width, uint3
     if (by_vectors)
         hipLaunchKernelGGL((k_assemble_x16<PER, RGB8>), dim3(tiles_x, tiles_y, n_frames), dim3(256), 0, c->stream,
                            reinterpret_cast<const uint32_t*>(gathered), width, height, tile_w, tile_h, tiles_x, plan, per_rank,
-                           frame_stride, reinterpret_cast<uint4*>(image));
+                           frame_stride, reinterpret_cast<uint4*>(image), sky);
     else
         hipLaunchKernelGGL((k_assemble<PIXEL, RGB8>), dim3((width + 255) / 256, height, n_frames), dim3(256), 0, c->stream, gathered,
-                           width, height, tile_w, tile_h, tiles_x, plan, per_rank, frame_stride, reinterpret_cast<PIXEL*>(image));
+                           width, height, tile_w, tile_h, tiles_x, plan, per_rank, frame_stride, reinterpret_cast<PIXEL*>(image), sky);
     RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
@@ -1664,6 +1721,53 @@ extern "C" int rt_assemble_frames(rt_ctx* c, const uint8_t* gathered, uint32_t p
                                                "rt_assemble_frames", n_frames, frame_stride);
     if (int r = use(c)) return r;
     return fail(c, RT_ERR_INVALID, "rt_assemble_frames: unknown pixel_format %u", pixel_format);
+}
+
+extern "C" int rt_assemble_frames_sky(rt_ctx* c, const uint8_t* gathered, uint32_t pixel_format, uint32_t width, uint32_t height,
+                                      uint32_t tile_w, uint32_t tile_h, uint32_t n_ranks, const uint32_t* owner, uint32_t round,
+                                      const CameraUniform* cameras, uint32_t n_frames, size_t rank_stride, size_t frame_stride,
+                                      uint8_t* images) {
+    if (!cameras) {
+        if (int r = use(c)) return r;
+        return fail(c, RT_ERR_INVALID, "rt_assemble_frames_sky: cameras is NULL");
+    }
+    if (pixel_format == RT_PIXEL_RGB8)
+        return assemble_tiles<uint32_t, true>(c, gathered, width, height, tile_w, tile_h, n_ranks, owner, round, rank_stride, images,
+                                              "rt_assemble_frames_sky", n_frames, frame_stride, cameras);
+    if (pixel_format == RT_PIXEL_RGBA8)
+        return assemble_tiles<uint32_t, false>(c, gathered, width, height, tile_w, tile_h, n_ranks, owner, round, rank_stride, images,
+                                               "rt_assemble_frames_sky", n_frames, frame_stride, cameras);
+    if (int r = use(c)) return r;
+    return fail(c, RT_ERR_INVALID, "rt_assemble_frames_sky: unknown pixel_format %u", pixel_format);
+}
+
+// Which tiles of the frame can show geometry from this camera: the frame's block mask, made now, read back, reduced.
+extern "C" int rt_tile_flags(rt_ctx* c, const CameraUniform* cam, uint32_t width, uint32_t height, uint32_t tile_w, uint32_t tile_h,
+                             uint8_t* flags) {
+    if (int r = use(c)) return r;
+    if (!c->has_grid) return fail(c, RT_ERR_STATE, "rt_tile_flags: no grid (call rt_build_grid or rt_set_grid_*)");
+    if (!cam || !flags || !width || !height || !tile_w || !tile_h) return fail(c, RT_ERR_INVALID, "rt_tile_flags: NULL or zero argument");
+    const uint32_t tiles_x = (width + tile_w - 1) / tile_w, tiles_y = (height + tile_h - 1) / tile_h;
+    memset(flags, 1, (size_t)tiles_x * tiles_y);
+    if ((tile_w & 7u) || (tile_h & 7u) || !c->params.cull_empty_blocks) return RT_OK;  // no mask wanted or possible: every tile is rendered
+    ShardMap m;
+    if (int r = make_shard(c, width, height, nullptr, &m, "rt_tile_flags")) return r;
+    const DevScene s = make_scene(c);
+    const DevFrame f = make_frame(c, cam, width, height);
+    const uint32_t* mask = nullptr;
+    c->last_cull = nullptr;
+    if (int r = cull_mask_for(c, s, f, m, &mask, true)) return r;
+    if (!mask) return RT_OK;
+    rt_cull* k = c->last_cull;
+    std::vector<uint32_t> host(k->words);
+    RT_HIP(c, hipMemcpyAsync(host.data(), mask, (size_t)k->words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t blocks_x = (width + 7u) >> 3, blocks_y = (height + 7u) >> 3, words_per_row = (blocks_x + 31u) >> 5;
+    memset(flags, 0, (size_t)tiles_x * tiles_y);
+    for (uint32_t by = 0; by < blocks_y; ++by)
+        for (uint32_t bx = 0; bx < blocks_x; ++bx)
+            if ((host[(size_t)by * words_per_row + (bx >> 5)] >> (bx & 31u)) & 1u) flags[(size_t)(by * 8u / tile_h) * tiles_x + bx * 8u / tile_w] = 1;
+    return RT_OK;
 }
 
 extern "C" int rt_assemble_frames_rgba8(rt_ctx* c, const uint8_t* gathered, uint32_t width, uint32_t height, uint32_t tile_w,

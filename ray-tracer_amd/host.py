@@ -449,6 +449,26 @@ class TraceCore:
                                             tab, len(owner) if owner is not None else 0, n_frames, rank_stride, frame_stride,
                                             _ptr(images)))
 
+    def tile_flags(self, cam, width, height, tile_w, tile_h):
+        """rt_tile_flags: uint8 per tile (row-major), 0 = the tile shows nothing but sky from this camera. Synchronous."""
+        n = (-(-width // tile_w)) * (-(-height // tile_h))
+        flags = np.empty(n, np.uint8)
+        self._ck(self._L.rt_tile_flags(self._h, _ref(cam, CameraUniform), width, height, tile_w, tile_h, _ptr(flags)))
+        return flags
+
+    def assemble_frames_sky(self, gathered, rgb8, width, height, tile_w, tile_h, n_ranks, owner, cams, rank_stride, frame_stride,
+                            images):
+        """rt_assemble_frames_sky: as assemble_frames, tiles whose owner entry is RT_OWNER_SKY filled from cams[j]."""
+        # owner / cams may be ctypes arrays made once by the caller (a table over every tile of a frame has thousands of entries)
+        tab = owner if isinstance(owner, C.Array) else (C.c_uint32 * len(owner))(*[int(k) for k in owner])
+        arr = cams
+        if not isinstance(cams, C.Array):
+            arr = (CameraUniform * len(cams))()
+            for j, cam in enumerate(cams):
+                C.memmove(C.byref(arr, j * C.sizeof(CameraUniform)), C.byref(cam), C.sizeof(CameraUniform))
+        self._ck(self._L.rt_assemble_frames_sky(self._h, _ptr(gathered), 1 if rgb8 else 0, width, height, tile_w, tile_h, n_ranks,
+                                                tab, len(tab), arr, len(arr), rank_stride, frame_stride, _ptr(images)))
+
     def debug_pixel(self, cam, width, height, px, py):
         info = RayDebugInfo()
         self._ck(self._L.rt_debug_pixel(self._h, _ref(cam, CameraUniform), width, height, px, py, C.byref(info)))

@@ -23,6 +23,11 @@ tiles of up to 64 consecutive frames in one to four launches (rt_render_frames),
 them in one launch, so launch, collective and host costs are paid once per group instead of once per frame, and
 the expensive pixel blocks of one frame overlap the other frames of the group. Groups are kept in flight like
 frames.
+Tiles that show nothing but sky need not travel at all (`enable_sparse`): which tiles those are follows from the camera
+alone (TraceCore.tile_flags: the frame's block mask reduced to tiles, identical on every rank), so for cameras announced
+ahead (`prepare_cameras`) the ranks deal only the other tiles among themselves, send only those, and rank 0's assemble
+kernel writes the sky tiles from the camera. On the bundled static model's frame a third of the 32x32 tiles are sky:
+as many bytes less on the links into rank 0, which is what bounds the frame rate at 8 GPUs.
 The tracer is passed in (`core`): the product passes a ray_tracer_amd.TraceCore; the CPU tests pass
 a stand-in so the sharding logic runs under gloo without a GPU.
 """
@@ -30,7 +35,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._lib import RtShard
+from ._lib import RT_OWNER_SKY, RtShard
 from .host import shard_pixels
 
 
@@ -223,6 +228,8 @@ class FrameSharder:
         # only waits for work queued on torch's current stream, and makes that stream wait for its completion.
         self.slots = [_Slot(self, device) for _ in range(max(1, frames_in_flight))]
         self.frame = 0
+        self.sparse, self._tile_flags, self._plans = False, {}, {}
+        self.last_wire_bytes = 0  # bytes one rank's block of the most recent group holds (what a rank sends)
         self.group, self.gslots, self.group_no, self.wire_bytes = 0, [], 0, 4
         self.local, self.packed, self.image = self.slots[0].local, self.slots[0].packed, self.slots[0].image
 
@@ -267,6 +274,58 @@ class FrameSharder:
         self.wire_bytes = 3 if rgb8 else 4
         self.gslots = [_GroupSlot(self, self.device) for _ in range(max(1, groups_in_flight))]
 
+    # ---- sky tiles stay at home
+    def enable_sparse(self):
+        """Groups whose cameras have all been announced (prepare_cameras) leave their sky tiles out: nobody renders or
+        sends them, rank 0 writes them from the camera. Other groups travel whole, as without this call."""
+        if self.mode != "rgba" or not self.gslots:
+            raise ValueError("sky tiles are left out of frame groups: mode 'rgba', enable_groups first")
+        if self.tile_w % 8 or self.tile_h % 8:
+            raise ValueError("tiles must be multiples of 8 pixels (the block mask's raster)")
+        if n_tiles(self.width, self.height, self.tile_w, self.tile_h) > 65536:
+            raise ValueError("more than 65 536 tiles: an owner table over the whole frame does not fit")
+        self.sparse = True
+
+    def prepare_cameras(self, cams):
+        """Classifies the tiles of every camera not seen before (one small synchronous GPU pass each, identical on every
+        rank). Call it ahead of the frames - at scene load for a fixed camera or a recorded path."""
+        for cam in cams:
+            key = bytes(cam)
+            if key not in self._tile_flags:
+                self._tile_flags[key] = np.asarray(self.core.tile_flags(cam, self.width, self.height, self.tile_w, self.tile_h), np.uint8) != 0
+
+    def _sparse_plan(self, cams):
+        """Who renders what for this group, or None when one of its cameras has not been announced. A tile is left out
+        only if it is sky in EVERY frame of the group (one launch renders the group with one shard); the kept tiles are
+        dealt among the ranks in the pattern of owner_table(weights), so a rank's tiles stay spread over the frame."""
+        keys = tuple(bytes(cam) for cam in cams)
+        plan = self._plans.get(keys)
+        if plan is not None:
+            return plan
+        if any(k not in self._tile_flags for k in keys):
+            return None
+        kept = np.zeros(n_tiles(self.width, self.height, self.tile_w, self.tile_h), bool)
+        for k in set(keys):
+            kept |= self._tile_flags[k]
+        owner = np.full(len(kept), RT_OWNER_SKY, np.uint32)
+        idx = np.flatnonzero(kept)
+        owner[idx] = np.resize(np.asarray(owner_table(self.weights or [1] * self.world), np.uint32), len(idx))
+        most = int(np.bincount(owner[idx], minlength=self.world).max()) if len(idx) else 0
+        plan = {"owner": [int(k) for k in owner], "per_rank": max(1, most) * self.tile_w * self.tile_h, "kept_tiles": int(kept.sum())}
+        plan["shard"] = RtShard(self.tile_w, self.tile_h, self.rank, owner=plan["owner"])
+        if hasattr(self.core, "_L"):  # the C ABI's caller: the table and the cameras as ctypes arrays, made once per plan
+            import ctypes as C
+            from ._lib import CameraUniform
+            plan["owner_c"] = (C.c_uint32 * len(plan["owner"]))(*plan["owner"])
+            arr = (CameraUniform * len(cams))()
+            for j, cam in enumerate(cams):
+                C.memmove(C.byref(arr, j * C.sizeof(CameraUniform)), C.byref(cam), C.sizeof(CameraUniform))
+            plan["cams_c"] = arr
+        if len(self._plans) > 64:
+            self._plans.clear()
+        self._plans[keys] = plan
+        return plan
+
     def trace_group(self, cams):
         """len(cams) <= group consecutive frames. On rank 0 returns the (len(cams), height*width, 4) uint8 pictures
         (valid until `groups_in_flight` further groups have been started); None on the other ranks."""
@@ -285,33 +344,47 @@ class FrameSharder:
 
     def _trace_group(self, cams, g, slot):
         rgb8 = self.wire_bytes == 3
+        plan = self._sparse_plan(cams) if self.sparse else None
+        # one rank's block of the gather: `group` frames of `stride` pixels each. With sky tiles left out a block holds
+        # fewer tiles; it sits at the front of the same buffers.
+        shard, stride = (plan["shard"], plan["per_rank"]) if plan else (self.shard, self.per_rank)
+        block = self.group * stride * self.wire_bytes  # bytes (unused frames of a short group travel too: a group is short only at the end of a path)
+        self.last_wire_bytes = block
+        local = slot.local.view(-1)[:block].view(self.group, stride, self.wire_bytes)
+        packed = slot.packed.view(-1)[:self.world * block].view(self.world, self.group, stride, self.wire_bytes) if self.rank == 0 else None
         for j in range(0, g, 16):  # one launch renders up to 16 frames
-            self.core.render_frames(cams[j:j + 16], self.width, self.height, shard=self.shard, max_bounces=self.max_bounces,
-                                    shadows=self.shadow, out=slot.local[j:min(g, j + 16)], rgb8=rgb8,
-                                    frame_stride=self.per_rank)
+            self.core.render_frames(cams[j:j + 16], self.width, self.height, shard=shard, max_bounces=self.max_bounces,
+                                    shadows=self.shadow, out=local[j:min(g, j + 16)], rgb8=rgb8, frame_stride=stride)
         if self.collective and self.native_comm:
-            # rt_gather_frames on the trace core's stream: whole per-rank blocks (unused frames of a short group
-            # travel too: a group is short only at the end of a path)
-            self.core.gather_frames(0, slot.local, slot.local.numel(), slot.packed)
+            # rt_gather_frames on the trace core's stream: whole per-rank blocks
+            self.core.gather_frames(0, local, block, packed)
         elif self.collective and self.host_gather:
             if slot.stream is not None:
                 slot.stream.synchronize()
-            mine = slot.local[:g].cpu()
+            mine = local[:g].cpu()
             parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
             dist.gather(mine, parts, dst=0)
             if self.rank == 0:
                 for r in range(self.world):
-                    slot.packed[r, :g].copy_(parts[r])
+                    packed[r, :g].copy_(parts[r])
         elif self.collective:
-            if g not in slot.views:  # tensor views are not free to make: once per group length
-                slot.views[g] = (slot.local[:g], [slot.packed[r, :g] for r in range(self.world)] if self.rank == 0 else None)
-            mine, parts = slot.views[g]
+            key = (g, stride)
+            if key not in slot.views:  # tensor views are not free to make: once per group length and layout
+                if len(slot.views) > 16:
+                    slot.views.clear()
+                slot.views[key] = (local[:g], [packed[r, :g] for r in range(self.world)] if self.rank == 0 else None)
+            mine, parts = slot.views[key]
             dist.gather(mine, parts, dst=0)
         if self.rank != 0:
             return None
-        src = slot.packed if self.collective else slot.local.unsqueeze(0)
-        self.core.assemble_frames(src, rgb8, self.width, self.height, self.tile_w, self.tile_h, self.world, self.owner, g,
-                                  self.group * self.per_rank, self.per_rank, slot.images[:g])
+        src = packed if self.collective else local.unsqueeze(0)
+        if plan:
+            self.core.assemble_frames_sky(src, rgb8, self.width, self.height, self.tile_w, self.tile_h, self.world,
+                                          plan.get("owner_c", plan["owner"]), plan.get("cams_c", cams), self.group * stride, stride,
+                                          slot.images[:g])
+        else:
+            self.core.assemble_frames(src, rgb8, self.width, self.height, self.tile_w, self.tile_h, self.world, self.owner, g,
+                                      self.group * stride, stride, slot.images[:g])
         return slot.images[:g]
 
     def _trace(self, cam, slot):

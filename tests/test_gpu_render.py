@@ -413,3 +413,79 @@ def test_unequal_shares_render_and_assemble(core, ob, rt, car_xyz9):
     with pytest.raises(rt.RtError) as e:
         core.assemble_frames(packed, True, w, h, tw, th, len(counts), owner, len(cams), len(cams) * per, per + per // 2, images)
     assert e.value.code == rt.RT_ERR_INVALID
+
+
+def test_sky_tiles_stay_at_home(core, ob, rt, car_xyz9):
+    """rt_tile_flags + RT_OWNER_SKY + rt_assemble_frames_sky: tiles that show nothing but sky are neither rendered nor
+    gathered; the assemble kernel writes them from the camera, byte for byte what rendering them would have given.
+    Three ranks played in turn on this GPU, both wire formats, both assemble kernels (tile widths that split into 16-byte
+    pieces and one that does not), cameras far away (mostly sky), at the start pose and inside the grid (no sky)."""
+    import torch
+    from ray_tracer_amd import sharding
+    tris = rt.triangles_from_xyz9(car_xyz9)
+    core.set_scene(None, tris)
+    core.set_materials(None)
+    core.build_grid()
+    scene = ob.Scene(None, ob.triangles_from_xyz9(car_xyz9))
+    world = 3
+    poses = [rt.Camera((900, 500, 1200), 3.7, -0.3), rt.Camera.for_scene("gltf"), rt.Camera((10, 30, 20), 0.7, -0.2)]
+    for (w, h, tw, th), rgb8 in (((320, 184, 32, 32), True), ((320, 184, 32, 16), False), ((203, 117, 24, 8), True)):
+        cams = [p.to_uniform(0.0, float(h)) for p in poses]
+        flags = [core.tile_flags(c, w, h, tw, th) for c in cams]
+        n_tiles = sharding.n_tiles(w, h, tw, th)
+        assert all(len(f) == n_tiles for f in flags)
+        assert 0 < flags[0].sum() < n_tiles // 2 and flags[2].all(), (flags[0].sum(), flags[2].sum(), n_tiles)
+        # a tile flagged sky holds no primary hit (the flags may keep more tiles than that, never fewer)
+        for cam, f in zip(cams, flags):
+            op, _, _ = ob.trace_primary(scene, ocam(ob, cam), w, h, shadow=False, params=oparams(ob, core.params), n_threads=8)
+            hit = (op["id"] != ob.MISS).reshape(h, w)
+            tiles_x = -(-w // tw)
+            for t in np.flatnonzero(f == 0):
+                ty, tx = divmod(int(t), tiles_x)
+                assert not hit[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].any(), f"tile {t} flagged sky but hit"
+        # one group of three frames: a tile stays at home only if it is sky in all three (here: none, the last camera is
+        # inside); then groups of the first two cameras, where many do
+        for group in (cams, cams[:2], cams[:1]):
+            kept = np.zeros(n_tiles, bool)
+            for cam in group:
+                kept |= flags[cams.index(cam)] != 0
+            owner = np.full(n_tiles, rt.RT_OWNER_SKY, np.uint32)
+            owner[kept] = np.resize(np.asarray(sharding.owner_table([1, 2, 2]), np.uint32), int(kept.sum()))
+            owner = [int(k) for k in owner]
+            shards = [rt.RtShard(tw, th, r, owner=owner) for r in range(world)]
+            per = max(1, max(rt.shard_pixels(w, h, s) for s in shards))
+            assert sum(rt.shard_pixels(w, h, s) for s in shards) == int(kept.sum()) * tw * th
+            packed = torch.full((world, len(group), per, 3 if rgb8 else 4), 77, dtype=torch.uint8, device="cuda")
+            for r, s in enumerate(shards):
+                core.render_frames(group, w, h, shard=s, max_bounces=1, shadows=True, out=packed[r], rgb8=rgb8, frame_stride=per)
+            images = torch.zeros((len(group), h * w, 4), dtype=torch.uint8, device="cuda")
+            core.assemble_frames_sky(packed, rgb8, w, h, tw, th, world, owner, group, len(group) * per, per, images)
+            core.sync()
+            for j, cam in enumerate(group):
+                want, _ = ob.render(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params), max_bounces=1, shadows=True)
+                got = images[j].cpu().numpy()
+                bad = np.flatnonzero((got != want).any(axis=1))
+                assert bad.size == 0, f"{w}x{h} tiles {tw}x{th} rgb8={rgb8}, group of {len(group)}, frame {j}: {bad.size} pixels differ, first {bad[:4]}"
+    # the sharder end to end with one rank: announced cameras take the sparse route, an unannounced one the whole one
+    w, h = 320, 184
+    cams = [p.to_uniform(0.0, float(h)) for p in poses]
+    sh = sharding.FrameSharder(core, w, h, 32, 32, rank=0, world=1, device="cuda", shadow=True, mode="rgba", max_bounces=1)
+    sh.enable_groups(group=2, groups_in_flight=2, rgb8=True)
+    sh.enable_sparse()
+    sh.prepare_cameras(cams[:2])
+    a = sh.trace_group(cams[:2])
+    sparse_bytes = sh.last_wire_bytes
+    b = sh.trace_group([cams[0], cams[2]])
+    assert sparse_bytes < sh.last_wire_bytes == 2 * sh.per_rank * 3
+    sh.synchronize()
+    core.set_stream(None)
+    for cam, pic in ((cams[0], a[0]), (cams[1], a[1]), (cams[0], b[0]), (cams[2], b[1])):
+        want, _ = ob.render(scene, ocam(ob, cam), w, h, params=oparams(ob, core.params), max_bounces=1, shadows=True)
+        assert np.array_equal(pic.cpu().numpy(), want)
+    # scenes the mask does not cover (boxes) flag every tile; sky entries without cameras are refused
+    core.set_scene(demo_boxes(ob), None)
+    core.build_grid()
+    assert core.tile_flags(cams[0], w, h, 32, 32).all()
+    with pytest.raises(rt.RtError):
+        core.assemble_frames(torch.zeros((1, 1, 64, 4), dtype=torch.uint8, device="cuda"), False, 8, 8, 8, 8, 1, [rt.RT_OWNER_SKY], 1, 64, 64,
+                             torch.zeros((1, 64, 4), dtype=torch.uint8, device="cuda"))

@@ -77,6 +77,42 @@ class OracleCore:
     def set_stream(self, stream):
         pass
 
+    def tile_flags(self, cam, width, height, tile_w, tile_h):
+        """Stand-in for rt_tile_flags: a tile without a primary hit shows nothing but sky (the GPU's mask is more
+        cautious, never less)."""
+        p, _, _ = self.ob.trace_primary(self.scene, cam, width, height, shadow=False, n_threads=2)
+        hit = (p["id"] != self.ob.MISS).reshape(height, width)
+        tiles_x, tiles_y = -(-width // tile_w), -(-height // tile_h)
+        flags = np.zeros(tiles_x * tiles_y, np.uint8)
+        for ty in range(tiles_y):
+            for tx in range(tiles_x):
+                flags[ty * tiles_x + tx] = hit[ty * tile_h:(ty + 1) * tile_h, tx * tile_w:(tx + 1) * tile_w].any()
+        return flags
+
+    def assemble_frames_sky(self, gathered, rgb8, width, height, tile_w, tile_h, n_ranks, owner, cams, rank_stride, frame_stride,
+                            images):
+        SKY = 0xFFFFFFFF
+        per = 3 if rgb8 else 4
+        flat = gathered.reshape(-1, per)
+        tiles_x = -(-width // tile_w)
+        for j, cam in enumerate(cams):
+            sky, _ = self.ob.render(self.scene, cam, width, height, max_bounces=1, n_threads=2)  # its missed pixels are the sky
+            count = {}
+            for t, r in enumerate(owner):
+                x0, y0 = (t % tiles_x) * tile_w, (t // tiles_x) * tile_h
+                if r != SKY:
+                    lt = count.get(r, 0)
+                    count[r] = lt + 1
+                for y in range(y0, min(height, y0 + tile_h)):
+                    for x in range(x0, min(width, x0 + tile_w)):
+                        if r == SKY:
+                            images[j, y * width + x] = torch.from_numpy(sky[y * width + x].copy())
+                        else:
+                            src = j * frame_stride + r * rank_stride + lt * tile_w * tile_h + (y - y0) * tile_w + (x - x0)
+                            images[j, y * width + x, :per] = flat[src]
+                            if rgb8:
+                                images[j, y * width + x, 3] = 255
+
     def assemble_tiles_rgba8(self, gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride=0):
         self._assemble(gathered, width, height, tile_w, tile_h, n_ranks, image, rank_stride, torch.uint8, 4)
 
@@ -157,6 +193,25 @@ def _worker(rank, world, port, tmp):
             open(os.path.join(tmp, "result_groups"), "w").write(str(int(ok3)))
         else:
             assert first is None and second is None
+        # sky tiles stay at home: announced cameras travel without them, an unannounced one travels whole
+        far = ob.camera_to_uniform((900, 500, 1200), 3.7, -0.3, 0.0, float(H))  # the model small in the frame: mostly sky
+        shs = sharding.FrameSharder(OracleCore(ob, scene), W, H, TW, TH, device="cpu", shadow=False, mode="rgba", max_bounces=1,
+                                    weights=weights)
+        shs.enable_groups(group=2, groups_in_flight=2, rgb8=(world == 2))
+        shs.enable_sparse()
+        shs.prepare_cameras([cam, far])
+        dense_block = shs.group * shs.per_rank * shs.wire_bytes
+        a = shs.trace_group([far, cam])
+        sparse_block = shs.last_wire_bytes
+        b = shs.trace_group([far, cam2])  # cam2 was not announced
+        whole_block = shs.last_wire_bytes
+        c = shs.trace_group([far])
+        if rank == 0:
+            ok4 = sparse_block < dense_block and whole_block == dense_block
+            for cm, pic in ((far, a[0]), (cam, a[1]), (far, b[0]), (cam2, b[1]), (far, c[0])):
+                want, _ = ob.render(scene, cm, W, H, max_bounces=1, n_threads=2)
+                ok4 = ok4 and np.array_equal(pic.numpy(), want)
+            open(os.path.join(tmp, "result_sparse"), "w").write(f"{int(ok4)} {sparse_block} {dense_block}")
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -175,6 +230,8 @@ def test_frame_sharding_two_ranks_gloo(tmp_path, world):
     assert ok == "1" and int(hits) > 1000
     assert open(tmp_path / "result_rgba").read() == "1"
     assert open(tmp_path / "result_groups").read() == "1"
+    ok, sparse_block, dense_block = open(tmp_path / "result_sparse").read().split()
+    assert ok == "1" and int(sparse_block) < int(dense_block), (sparse_block, dense_block)
 
 
 def test_tile_bookkeeping():

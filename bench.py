@@ -66,6 +66,10 @@ FRAMES_IN_FLIGHT = int(os.environ.get("RT_BENCH_IN_FLIGHT", "3"))
 # behind its rendering.
 GROUP = int(os.environ.get("RT_BENCH_GROUP", "4" if WORKLOAD == "massive8k" else "32"))
 GROUPS_IN_FLIGHT = int(os.environ.get("RT_BENCH_GROUPS_IN_FLIGHT", "2"))
+# Tiles that show nothing but sky from the frame's camera are neither rendered nor sent at N > 1: which they are follows
+# from the camera alone, and rank 0's assemble kernel writes them (byte-identical pictures; RT_BENCH_SPARSE=0: every tile
+# travels).
+SPARSE = os.environ.get("RT_BENCH_SPARSE", "1") == "1" and WORKLOAD != "massive8k"
 PREHEAT_MS = float(os.environ.get("RT_BENCH_PREHEAT_MS", "150"))  # untimed steps before the warm-up steps (see main)
 
 
@@ -189,6 +193,9 @@ def same_route_single_gpu(core, sharding, cam, dev, steps):
                                max_bounces=1, collective=False)
     sh.native_comm = False
     sh.enable_groups(GROUP, GROUPS_IN_FLIGHT, rgb8=True)
+    if SPARSE:
+        sh.enable_sparse()
+        sh.prepare_cameras([cam])
     cams = [cam] * GROUP
     for _ in range(2):
         sh.trace_group(cams)
@@ -417,6 +424,9 @@ def main():
         sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
                                    frames_in_flight=1, max_bounces=1, collective=True, weights=weights, host_gather=rehearsal)
         sh.enable_groups(GROUP, GROUPS_IN_FLIGHT, rgb8=os.environ.get("RT_BENCH_WIRE", "rgb") == "rgb")  # the constant alpha byte stays at home
+        if SPARSE:
+            sh.enable_sparse()
+            sh.prepare_cameras([cam])  # one small synchronous pass on every rank, before the timed region
         if os.environ.get("RT_BENCH_TRACE"):  # development: where every rank is, every few seconds
             import threading
 
@@ -451,11 +461,19 @@ def main():
     # Untimed, before the W warm-up steps: the same steps for PREHEAT_MS of wall time, so that the timed region runs at
     # the clocks a renderer sees in steady state however few steps the caller asks for (the first tens of milliseconds
     # after an idle period run ~6 % slower: clock ramp).
+    # At N > 1 every pass holds a collective, so the ranks must make the same number of passes: rank 0's clock decides
+    # and the decision is handed round after every pass (a rank that went on alone would be one gather ahead for good).
     t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < PREHEAT_MS:
+    go_on = PREHEAT_MS > 0
+    while go_on:
         for _ in range(8 if not multi else GROUP):
             step()
         sync()
+        go_on = (time.perf_counter() - t_pre) * 1e3 < PREHEAT_MS
+        if multi and world > 1:
+            word = torch.tensor([1 if go_on else 0], dtype=torch.int32, device="cpu" if rehearsal else dev)
+            dist.broadcast(word, 0)
+            go_on = bool(int(word.item()))
     for _ in range(args.warmup):
         step()
     sync()
@@ -543,6 +561,12 @@ def main():
                                     f"{GROUP} frames, RGB8, assembled to RGBA8, no collective")
         if multi and base_ms:
             out["speedup_vs_scaling_base"] = base_ms / ms_per_step
+        if multi:
+            plan = sh._sparse_plan([cam]) if sh.sparse else None
+            tiles = sharding.n_tiles(WIDTH, HEIGHT, TILE, TILE)
+            out["config"]["tiles"] = tiles
+            out["config"]["tiles_rendered_and_sent"] = plan["kept_tiles"] if plan else tiles
+            out["config"]["wire_bytes_per_frame_per_rank"] = sh.last_wire_bytes // GROUP
         if multi:  # false: the gathers of this line are torch.distributed's (or the rehearsal's), not rt_gather_frames
             out["native_comm"] = bool(getattr(core, "comm_size", 0))
         out["timed_kernel"] = ("k_trace_primary_lean<shadow>: rt_hit records" if not multi else

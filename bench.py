@@ -264,6 +264,27 @@ def cpu_baseline(xyz9, width, height):
             "single_thread_Mrays": n1 / one / 1e6, "grid_traversal_port_Mrays": len(ro) / dda / 1e6}
 
 
+def preheat(step, sync, steps_per_pass, dist, device):
+    """Untimed passes of `steps_per_pass` steps + sync for PREHEAT_MS of wall time. At N > 1 (dist given) every pass
+    holds a collective, so the ranks must make the same number of passes: rank 0's clock decides and the decision is
+    handed round after every pass (a rank that went on alone would stay one gather ahead of the others for good).
+    Returns the number of passes."""
+    t_pre = time.perf_counter()
+    go_on = PREHEAT_MS > 0
+    passes = 0
+    while go_on:
+        for _ in range(steps_per_pass):
+            step()
+        sync()
+        passes += 1
+        go_on = (time.perf_counter() - t_pre) * 1e3 < PREHEAT_MS
+        if dist is not None:
+            word = torch.tensor([1 if go_on else 0], dtype=torch.int32, device=device)
+            dist.broadcast(word, 0)
+            go_on = bool(int(word.item()))
+    return passes
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,8 +339,20 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
         ones = torch.ones(1)
         dist.all_reduce(ones)
+        # the pre-heat loop with ranks of different speed (a pass = one collective): every rank must make as many passes
+        count = torch.zeros(1)
+
+        def slow_pass():
+            time.sleep(0.004 * (1 + rank))
+            dist.all_reduce(count.add_(1))
+
+        passes = torch.tensor([float(preheat(lambda: None, slow_pass, 1, dist if world > 1 else None, "cpu"))])
+        lo, hi = passes.clone(), passes.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if rank == 0:
-            emit(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(ones.item()), "steps": args.steps, "warmup": args.warmup}))
+            emit(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(ones.item()), "steps": args.steps, "warmup": args.warmup,
+                             "preheat_passes_min": int(lo.item()), "preheat_passes_max": int(hi.item())}))
         dist.destroy_process_group()
         return
     # Rehearsal on a one-GPU box: RT_BENCH_ONE_GPU=1 puts every rank on GPU 0 and uses gloo (RCCL refuses two
@@ -461,19 +494,7 @@ def main():
     # Untimed, before the W warm-up steps: the same steps for PREHEAT_MS of wall time, so that the timed region runs at
     # the clocks a renderer sees in steady state however few steps the caller asks for (the first tens of milliseconds
     # after an idle period run ~6 % slower: clock ramp).
-    # At N > 1 every pass holds a collective, so the ranks must make the same number of passes: rank 0's clock decides
-    # and the decision is handed round after every pass (a rank that went on alone would be one gather ahead for good).
-    t_pre = time.perf_counter()
-    go_on = PREHEAT_MS > 0
-    while go_on:
-        for _ in range(8 if not multi else GROUP):
-            step()
-        sync()
-        go_on = (time.perf_counter() - t_pre) * 1e3 < PREHEAT_MS
-        if multi and world > 1:
-            word = torch.tensor([1 if go_on else 0], dtype=torch.int32, device="cpu" if rehearsal else dev)
-            dist.broadcast(word, 0)
-            go_on = bool(int(word.item()))
+    preheat(step, sync, 8 if not multi else GROUP, dist if multi and world > 1 else None, "cpu" if rehearsal else dev)
     for _ in range(args.warmup):
         step()
     sync()

@@ -564,9 +564,19 @@ __device__ inline bool trace_ray(const DevScene& s, V3 o, const RayDir& rd, HitR
         t_max.x += ax ? t_delta.x : 0.0f;
         t_max.y += ay ? t_delta.y : 0.0f;
         t_max.z += az ? t_delta.z : 0.0f;
-        if constexpr (X == 4) {  // timing probe only (wrong answers): every lane takes the first lane's cell record, by a scalar load
-            const v2i v = llvm_s_buffer_load_v2i32(cells_d, __builtin_amdgcn_readfirstlane((int)idx) * 8, 0);
-            cell = make_uint2((uint32_t)v.x, (uint32_t)v.y);
+        if constexpr (X == 4) {
+            // Experiment (development builds, or the whole library with -DRT_SCALAR_CELLS): when every lane still in the loop
+            // asks for the SAME cell record, one scalar load serves the wave (through the scalar cache, off the vector
+            // memory path); lanes in different cells keep the vector load. Bit-identical; measured 1 % slower than the
+            // vector load alone on the 1080p frame of the static model (the test per step costs what the load saves), and
+            // 4 % slower when the list scan also takes its "same list in every lane" answer from here.
+            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+            if (__builtin_amdgcn_ballot_w64(idx != i0) == 0ull) {
+                const v2i v = llvm_s_buffer_load_v2i32(cells_d, (int)(i0 * 8u), 0);
+                cell = make_uint2((uint32_t)v.x, (uint32_t)v.y);
+            } else {
+                cell = cell_rec(idx);
+            }
         } else {
             cell = cell_rec(idx);
         }
@@ -779,7 +789,12 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
         const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
         HitRec h;
         n_rays++;
-        if (trace_ray<WGSL, false, STATS, BOXES, TEX, WIDE>(s, o, rd, h, ctr)) {
+#ifdef RT_SCALAR_CELLS
+        constexpr int XB = LATE && !FRAMES ? 4 : 0;
+#else
+        constexpr int XB = 0;
+#endif
+        if (trace_ray<WGSL, false, STATS, BOXES, TEX, WIDE, XB>(s, o, rd, h, ctr)) {
             n_ph++;
             ph = make_uint2(h.id, __float_as_uint(h.t));
             if (SHADOW) {
@@ -792,7 +807,7 @@ __device__ inline void trace_primary_block(const DevScene& s, const DevFrame& f,
                 n_sr++;
                 // LATE: the kernel's leading arguments are PrimaryArgs' (checked where the kernels are declared)
                 const RayDir to_light = LATE ? late_shadow_dir(a_frame) : f.shadow;
-                if (trace_ray<WGSL, true, STATS, BOXES, TEX, WIDE>(s, so, to_light, oh, ctr)) {
+                if (trace_ray<WGSL, true, STATS, BOXES, TEX, WIDE, XB>(s, so, to_light, oh, ctr)) {
                     n_sh++;
                     sh = make_uint2(oh.id, __float_as_uint(oh.t));
                 }

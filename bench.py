@@ -162,8 +162,8 @@ def streaming_leg(rt, dev, steps, warmup):
            "cell_records_fetched": mov["cell_records_fetched"], "ref_records_fetched": mov["ref_records_fetched"],
            "ref_records_staged": mov["ref_records_staged"]}
     if repack:
-        out["fetched_note"] = ("the fetch counters are the plain loop's (the counting kernel); the timed kernel asks for the same cell "
-                               "records and, where it deals pairs out, for exactly the list entries, without look-ahead or staging")
+        out["fetched_note"] = ("counted by the counting build of the timed kernel (k_trace_primary_repack<count>): a cell record per step "
+                               "of a ray still followed, a reference record per look-ahead load of the plain scan and one per dealt pair")
     # What reaches HBM (hardware counters of the same command, committed): `frac` is THAT over the HBM peak. The
     # algorithmic figure stays beside it: neighbouring rays share cells, so most of those bytes are cache hits.
     out["algorithmic_GBps"] = achieved

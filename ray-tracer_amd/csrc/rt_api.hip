@@ -820,7 +820,8 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
     // the two counting builds (1: the reference's work, 2: this library's fetches) are the general kernels; the second
     // follows the frame's block mask as the timed kernel does (a block that is not traced fetches nothing)
     const uint32_t* nm = nullptr;
-    if (stats == 2 && may_alloc && c->tex_mode != 2 && !wide_grid(s))
+    const bool count_repack = stats == 2 && c->params.repack_candidates && s.nb == 0 && c->tex_mode != 2 && !c->params.heavy_block_threshold && !wide_grid(s);
+    if (stats == 2 && may_alloc && c->tex_mode != 2 && !wide_grid(s) && !count_repack)
         if (int r = cull_mask_for(c, s, f, m, &nm, true)) return r;
     if (wide_grid(s)) {
         if (stats == 2)
@@ -829,6 +830,9 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
             hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 1, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
         else
             hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 0, true, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
+    } else if (count_repack) {
+        // the counting build of the kernel such a frame is traced with (no mask there, no staging: pairs are dealt)
+        hipLaunchKernelGGL((k_trace_primary_repack<WGSL, SHADOW, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st);
     } else if (stats == 2) {
         hipLaunchKernelGGL((k_trace_primary<WGSL, SHADOW, 2, true, true>), grid, dim3(256), 0, c->stream, s, f, m, op, os, st, nm);
     } else if (stats) {
@@ -868,7 +872,7 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
                 if (int r = mark_in_flight(c)) return r;
         } else if (!plan && c->params.repack_candidates) {
             // rays of a wave in different cells: (ray, candidate) pairs dealt out again to the lanes (trace_ray_repack)
-            hipLaunchKernelGGL((k_trace_primary_repack<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os);
+            hipLaunchKernelGGL((k_trace_primary_repack<WGSL, SHADOW>), grid, dim3(256), 0, c->stream, s, f, m, op, os, (unsigned long long*)nullptr);
         } else if (plan) {
             const BlockPlan bp = make_block_plan(plan, c->params.heavy_block_threshold);
             hipLaunchKernelGGL((k_trace_primary_planned<WGSL, SHADOW>), dim3(grid.x + PLAN_LEAD_WGS), dim3(256), 0, c->stream, s, f, m, bp, op, os);

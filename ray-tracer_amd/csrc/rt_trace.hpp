@@ -129,6 +129,7 @@ struct Counters {
     // directly (48 bytes each, the look-ahead record included) and reference records copied into LDS for the wave
     uint32_t cell_recs, ref_recs, staged_recs;
     uint32_t cell_recs_uniform;  // of cell_recs: fetched while every active lane of the wave asked for the same record
+    uint32_t dealt_recs;         // trace_ray_repack: reference records this lane read for pairs dealt to it (added to ref_recs)
 };
 
 struct HitRec {
@@ -1040,8 +1041,12 @@ __device__ inline uint32_t wave_running_max(uint32_t x) {
 // lane scanning its own list (rounds of 64 pairs against the longest list of the wave, weighed by what a round and a
 // trip of the plain loop cost in instructions; 2 deals less readily: measured, slower, as is a more eager rule), the
 // plain scan otherwise.
-template <bool WGSL, bool ANY, int MODE = 1, bool TEX = false>
-__device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& rd, bool active, HitRec& out, RepackLds& L) {
+// COUNT: also count what the lanes ask the memory system for (Counters::cell_recs, ref_recs, as trace_ray<STATS = 2> does
+// for the plain loop): a cell record per step of a ray that is still followed, a reference record per look-ahead load of
+// the plain scan and one per dealt pair.
+template <bool WGSL, bool ANY, int MODE = 1, bool TEX = false, bool COUNT = false>
+__device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& rd, bool active, HitRec& out, RepackLds& L,
+                                        Counters* ctr = nullptr) {
     const uint32_t lane = threadIdx.x & 63;
     float closest = 1e10f;
     uint32_t best_ref = MISS;
@@ -1084,6 +1089,7 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
     uint32_t arrival = 0;
     uint32_t idx = alive ? (cx + 1u) + (cy + 1u) * s.px + (cz + 1u) * s.pxy : 0u;  // 0: a border cell, a sentinel
     uint2 cell = buf_load8(cells_d, idx);
+    if (COUNT && alive) ctr->cell_recs++;
     uint32_t left = s.max_steps;
     alive = alive && left != 0 && cell.y != CELL_SENTINEL;
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {  // the same in every lane
@@ -1095,6 +1101,7 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
         const uint32_t idx_next = alive ? idx + (ax ? dix : (ay ? diy : diz)) : 0u;
         RT_CHECK(idx_next < s.n_bordered, CHECK_CELL, idx_next, s.n_bordered);
         const uint2 cell_next = buf_load8(cells_d, idx_next);
+        if (COUNT && alive) ctr->cell_recs++;
         const uint32_t n = alive ? cell.y : 0u;
         const uint32_t incl = wave_prefix_sum(n);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1126,11 +1133,14 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
                 uint32_t r = cell.x;
                 const uint32_t r_end = r + n;
                 float4 a0 = buf_load16<0>(refs_d, r), a1 = buf_load16<16>(refs_d, r), a2 = buf_load16<32>(refs_d, r);
+                if (COUNT) ctr->ref_recs++;
                 for (;;) {
                     const float4 b0 = buf_load16<0>(refs_d, r + 1), b1 = buf_load16<16>(refs_d, r + 1), b2 = buf_load16<32>(refs_d, r + 1);
+                    if (COUNT) ctr->ref_recs++;
                     if (test(a0, a1, a2, r)) break;
                     if (++r == r_end) break;
                     a0 = buf_load16<0>(refs_d, r + 1), a1 = buf_load16<16>(refs_d, r + 1), a2 = buf_load16<32>(refs_d, r + 1);
+                    if (COUNT) ctr->ref_recs++;
                     if (test(b0, b1, b2, r)) break;
                     if (++r == r_end) break;
                 }
@@ -1155,6 +1165,7 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
                     const uint32_t rec = __float_as_uint(df.w) + k;
                     RT_CHECK(j < 64u && rec < s.n_refs, CHECK_DEAL, j, rec);
                     const float4 c0 = buf_load16<0>(refs_d, rec), c1 = buf_load16<16>(refs_d, rec), c2 = buf_load16<32>(refs_d, rec);
+                    if (COUNT) ctr->dealt_recs++;
                     const float4 oa = L.o_arrival[j];
                     if (!(__float_as_uint(c1.w) & __float_as_uint(oa.w))) {
                         const RayPk rp = make_ray_pk(v3(oa.x, oa.y, oa.z), v3(df.x, df.y, df.z));
@@ -1218,53 +1229,118 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
     out = HitRec{closest, MISS, best_ref};
     if (got) out.id = __float_as_uint(buf_load16<0>(refs_d, best_ref).w);  // the hit record's id, read once at the end
     if (literal) {
-        Counters ctr{};
-        got = trace_ray<WGSL, ANY, 0, false, TEX, false, 2>(s, o, rd, out, ctr);  // the form without an LDS buffer
+        Counters none{};
+        // Origin and direction go through an empty asm and the direction record is made again from them (the same
+        // function, the same bits): otherwise what the set-up above derived - start cell, step signs - is kept in
+        // registers, or spilled, through the whole loop for this rare path.
+        V3 o2 = o, d2 = rd.d;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(o2.x), "+v"(o2.y), "+v"(o2.z), "+v"(d2.x), "+v"(d2.y), "+v"(d2.z));
+#endif
+        const RayDir rd2 = make_ray_dir<WGSL>(d2, s.cell_size, s.px, s.pxy);
+        got = trace_ray<WGSL, ANY, 0, false, TEX, false, 2>(s, o2, rd2, out, none);  // the form without an LDS buffer
     }
     return active && got;
 }
 
 
-// k_trace_primary with trace_ray_repack as the traversal: every lane of a wave enters both traversals, with or without
-// a ray of its own.
-template <bool WGSL, bool SHADOW>
-__global__ __launch_bounds__(256, 6) void k_trace_primary_repack(DevScene s, DevFrame f, ShardMap m, uint2* __restrict__ out_p,
-                                                              uint2* __restrict__ out_s) {
-    __shared__ RepackLds repack[4];
-    const uint32_t lane = threadIdx.x & 63, w4 = threadIdx.x >> 6;
+// Where a lane's pixel is: recomputed from the thread index wherever it is needed (before the primary traversal, between
+// the two traversals, at the stores) instead of being carried in vector registers through both traversals, with the
+// frame and the tile map read again from the kernel-argument segment each time instead of sitting in scalar registers
+// (kept, the compiler spilled five vector registers: 24 bytes of scratch per lane written and read back through HBM).
+// `tid` and the segment pointer go through an empty asm so that the compiler cannot merge the copies.
+struct RepackPixel {
+    uint32_t lt, lx, ly, px, py;
+    bool in_tile, live;
+};
+__device__ inline void late_frame_and_map(DevFrame& f, ShardMap& m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) uint8_t* KernArg;
+    KernArg base = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    load_kernarg(f, reinterpret_cast<const __attribute__((address_space(4))) DevFrame*>(base + offsetof(PrimaryArgs, f)));
+    load_kernarg(m, reinterpret_cast<const __attribute__((address_space(4))) ShardMap*>(base + offsetof(PrimaryArgs, m)));
+#endif
+}
+__device__ inline RepackPixel repack_pixel(const DevFrame& f, const ShardMap& m) {
+    uint32_t tid = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(tid));
+#endif
+    RepackPixel q;
+    const uint32_t lane = tid & 63, w4 = tid >> 6;
     const uint32_t blk_x = (m.sub_x + 1) / 2, blk_y = (m.sub_y + 1) / 2;  // 16x16 blocks per tile
     const uint32_t blk_per_tile = blk_x * blk_y;
-    const uint32_t lt = blockIdx.x / blk_per_tile, blk = blockIdx.x % blk_per_tile;
-    if (lt >= m.n_local) return;  // whole workgroup
+    q.lt = blockIdx.x / blk_per_tile;
+    const uint32_t blk = blockIdx.x % blk_per_tile;
     const uint32_t sub_x = (blk % blk_x) * 2 + (w4 & 1), sub_y = (blk / blk_x) * 2 + (w4 >> 1);
-    const uint32_t lx = sub_x * 8 + (lane & 7), ly = sub_y * 8 + (lane >> 3);
-    const uint32_t tile = shard_tile(m, lt);
-    const uint32_t px = (tile % m.tiles_x) * m.tile_w + lx, py = (tile / m.tiles_x) * m.tile_h + ly;
-    const bool in_tile = lx < m.tile_w && ly < m.tile_h;
-    const bool live = in_tile && px < f.width && py < f.height;
-    RepackLds& L = repack[w4 & 3];
+    q.lx = sub_x * 8 + (lane & 7), q.ly = sub_y * 8 + (lane >> 3);
+    const uint32_t tile = shard_tile(m, q.lt);
+    q.px = (tile % m.tiles_x) * m.tile_w + q.lx, q.py = (tile / m.tiles_x) * m.tile_h + q.ly;
+    q.in_tile = q.lx < m.tile_w && q.ly < m.tile_h;
+    q.live = q.in_tile && q.px < f.width && q.py < f.height;
+    return q;
+}
+
+// k_trace_primary with trace_ray_repack as the traversal: every lane of a wave enters both traversals, with or without
+// a ray of its own. The kernel's leading arguments are PrimaryArgs' (scene, frame, tile map, the two output arrays):
+// the frame and the map are read through late_frame_and_map, never through the parameters.
+// COUNT: the counting build (rt_params.collect_stats = 2): rays, hits, and the records the lanes ask for.
+template <bool WGSL, bool SHADOW, bool COUNT = false>
+__global__ __launch_bounds__(256, 6) void k_trace_primary_repack(DevScene s, DevFrame, ShardMap, uint2* __restrict__ out_p,
+                                                              uint2* __restrict__ out_s, unsigned long long* stats) {
+    __shared__ RepackLds repack[4];
+    RepackLds& L = repack[(threadIdx.x >> 6) & 3];
     uint2 ph = make_uint2(MISS, 0u), sh = make_uint2(MISS, 0u);
-    const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
-    const V3 d = primary_dir(f, live ? px : 0u, live ? py : 0u);
-    const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
     HitRec h;
-    const bool hit = trace_ray_repack<WGSL, false>(s, o, rd, live, h, L);
+    bool hit;
+    Counters ctr{};
+    unsigned long long n_rays = 0, n_sh = 0;
+    {
+        DevFrame f;
+        ShardMap m;
+        late_frame_and_map(f, m);
+        const uint32_t blk_per_tile = ((m.sub_x + 1) / 2) * ((m.sub_y + 1) / 2);
+        if (blockIdx.x / blk_per_tile >= m.n_local) return;  // whole workgroup
+        const RepackPixel q = repack_pixel(f, m);
+        const V3 d = primary_dir(f, q.live ? q.px : 0u, q.live ? q.py : 0u);
+        const RayDir rd = make_ray_dir<WGSL>(d, s.cell_size, s.px, s.pxy);
+        hit = trace_ray_repack<WGSL, false, 1, false, COUNT>(s, v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]), rd, q.live, h, L, &ctr);
+        if (COUNT && q.live) n_rays++;
+    }
     if (hit) ph = make_uint2(h.id, __float_as_uint(h.t));
     if (SHADOW) {
+        DevFrame f;
+        ShardMap m;
+        late_frame_and_map(f, m);
+        const V3 o = v3(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2]);
         V3 so = o;
         if (hit) {
+            const RepackPixel q = repack_pixel(f, m);
+            const V3 d = primary_dir(f, q.px, q.py);  // the same arithmetic on the same pixel: the same bits
             const V3 pos = o + d * h.t;
             V3 n = hit_normal(s, h, pos);
             if (dot(n, d) > 0.0f) n = neg(n);
             so = pos + n * f.shadow_offset;
         }
         HitRec oh;
-        if (trace_ray_repack<WGSL, true>(s, so, f.shadow, hit, oh, L)) sh = make_uint2(oh.id, __float_as_uint(oh.t));
+        if (trace_ray_repack<WGSL, true, 1, false, COUNT>(s, so, late_shadow_dir((uint32_t)offsetof(PrimaryArgs, f)), hit, oh, L, &ctr)) {
+            sh = make_uint2(oh.id, __float_as_uint(oh.t));
+            n_sh++;
+        }
     }
-    if (in_tile) {
-        const size_t oi = (size_t)lt * m.tile_w * m.tile_h + (size_t)ly * m.tile_w + lx;
-        out_p[oi] = ph;
-        if (SHADOW) out_s[oi] = sh;
+    if (COUNT) {
+        ctr.ref_recs += ctr.dealt_recs;
+        flush_stats(stats, n_rays + (hit ? 1u : 0u), hit ? 1u : 0u, hit && SHADOW ? 1u : 0u, n_sh, ctr);
+    }
+    DevFrame f;
+    ShardMap m;
+    late_frame_and_map(f, m);
+    const RepackPixel q = repack_pixel(f, m);
+    if (q.in_tile) {
+        const size_t oi = (size_t)q.lt * m.tile_w * m.tile_h + (size_t)q.ly * m.tile_w + q.lx;
+        late_arg_ptr(offsetof(PrimaryArgs, out_p))[oi] = ph;
+        if (SHADOW) late_arg_ptr(offsetof(PrimaryArgs, out_s))[oi] = sh;
     }
 }
 

@@ -60,6 +60,37 @@ def test_rays_in_different_cells_equal_the_oracle(rt, ob, wgsl):
         on.close(), off.close()
 
 
+def test_counting_build_of_the_dealing_kernel(rt):
+    """collect_stats = 2 with repack_candidates on runs the counting build of k_trace_primary_repack: the records are
+    the uncounted kernel's, rays and hits are the plain counting kernel's, and the fetch counters describe the dealing
+    kernel (nothing staged; no more reference records than the plain loop with its look-ahead asks for, no fewer cell
+    records than the plain loop behind the frame's block mask)."""
+    xyz9 = random_soup(20000, 5)
+    on, off = pair(rt, rt.triangles_from_xyz9(xyz9), cell_size=4.0)
+    try:
+        w, h = 256, 144
+        for pos, yaw, pitch in (((0, 0, 0), 0.4, 0.1), ((0, 20, 140), math.pi, -0.1)):
+            cam = rt.Camera(pos, yaw, pitch).to_uniform(0.0, float(h))
+            p, s = same(on, off, cam, w, h, "uncounted")
+            got = {}
+            for name, core in (("on", on), ("off", off)):
+                core.set_collect_stats(2)
+                pc, sc = core.trace_primary(cam, w, h)
+                got[name] = core.stats()
+                core.set_collect_stats(0)
+                assert_hits_equal(pc, p, f"{name}: primary records of the counting build")
+                assert_hits_equal(sc, s, f"{name}: shadow records of the counting build")
+            a, b = got["on"], got["off"]
+            for k in ("rays", "primary_hits", "shadow_rays", "shadow_hits"):
+                assert a[k] == b[k], (k, a[k], b[k])
+            assert a["rays"] == w * h + int((p["id"] != rt.RT_MISS).sum())
+            assert a["ref_records_staged"] == 0
+            assert a["cell_records_fetched"] >= b["cell_records_fetched"] > 0
+            assert 0 < a["ref_records_fetched"] <= b["ref_records_fetched"] + b["ref_records_staged"] * 64
+    finally:
+        on.close(), off.close()
+
+
 def test_bundled_models_shards_and_step_limit(rt, ob, car_xyz9, phoenix_xyz9):
     for xyz9, pos, yaw, pitch in ((car_xyz9, (200, 200, 300), 3.35, -0.28), (phoenix_xyz9, (-300, 250, 600), 2.7, -0.2)):
         for kw in ({}, {"max_dda_steps": 12}, {"wgsl_compat": 1}):

@@ -1044,6 +1044,17 @@ __device__ inline uint32_t wave_running_max(uint32_t x) {
 // COUNT: also count what the lanes ask the memory system for (Counters::cell_recs, ref_recs, as trace_ray<STATS = 2> does
 // for the plain loop): a cell record per step of a ray that is still followed, a reference record per look-ahead load of
 // the plain scan and one per dealt pair.
+// Timing probe (experiment builds, make alt ALT=-DRT_PROBE_EXTRA_LOAD): one more 8-byte load of every candidate record,
+// from the cache line already asked for, its result unused: what eight bytes per record cost on the address path.
+#ifdef RT_PROBE_EXTRA_LOAD
+#define RT_PROBE_LOAD(R)                                             \
+    {                                                                \
+        const v2i probe_x = llvm_struct_buffer_load_v2i32(refs_d, (int)(R), 8, 0, 0); \
+        asm volatile("" ::"v"(probe_x.x), "v"(probe_x.y));           \
+    }
+#else
+#define RT_PROBE_LOAD(R)
+#endif
 template <bool WGSL, bool ANY, int MODE = 1, bool TEX = false, bool COUNT = false>
 __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& rd, bool active, HitRec& out, RepackLds& L,
                                         Counters* ctr = nullptr) {
@@ -1136,10 +1147,12 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
                 if (COUNT) ctr->ref_recs++;
                 for (;;) {
                     const float4 b0 = buf_load16<0>(refs_d, r + 1), b1 = buf_load16<16>(refs_d, r + 1), b2 = buf_load16<32>(refs_d, r + 1);
+                    RT_PROBE_LOAD(r + 1)
                     if (COUNT) ctr->ref_recs++;
                     if (test(a0, a1, a2, r)) break;
                     if (++r == r_end) break;
                     a0 = buf_load16<0>(refs_d, r + 1), a1 = buf_load16<16>(refs_d, r + 1), a2 = buf_load16<32>(refs_d, r + 1);
+                    RT_PROBE_LOAD(r + 1)
                     if (COUNT) ctr->ref_recs++;
                     if (test(b0, b1, b2, r)) break;
                     if (++r == r_end) break;
@@ -1165,6 +1178,7 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
                     const uint32_t rec = __float_as_uint(df.w) + k;
                     RT_CHECK(j < 64u && rec < s.n_refs, CHECK_DEAL, j, rec);
                     const float4 c0 = buf_load16<0>(refs_d, rec), c1 = buf_load16<16>(refs_d, rec), c2 = buf_load16<32>(refs_d, rec);
+                    RT_PROBE_LOAD(rec)
                     if (COUNT) ctr->dealt_recs++;
                     const float4 oa = L.o_arrival[j];
                     if (!(__float_as_uint(c1.w) & __float_as_uint(oa.w))) {
@@ -1286,8 +1300,14 @@ __device__ inline RepackPixel repack_pixel(const DevFrame& f, const ShardMap& m)
 // a ray of its own. The kernel's leading arguments are PrimaryArgs' (scene, frame, tile map, the two output arrays):
 // the frame and the map are read through late_frame_and_map, never through the parameters.
 // COUNT: the counting build (rt_params.collect_stats = 2): rays, hits, and the records the lanes ask for.
+#ifndef RT_REPACK_WAVES
+// Waves per SIMD the dealing kernel is held to. Seven (72 vector registers, two of them spilled outside the loops: 12 bytes
+// of scratch per lane) against six (74 registers, no scratch), same process, records identical: the scene that does not
+// fit the caches (10 M triangles, 3840x2160) 1.84 against 1.94 ms per frame, the animated model 151 against 148 us.
+#define RT_REPACK_WAVES 7
+#endif
 template <bool WGSL, bool SHADOW, bool COUNT = false>
-__global__ __launch_bounds__(256, 6) void k_trace_primary_repack(DevScene s, DevFrame, ShardMap, uint2* __restrict__ out_p,
+__global__ __launch_bounds__(256, RT_REPACK_WAVES) void k_trace_primary_repack(DevScene s, DevFrame, ShardMap, uint2* __restrict__ out_p,
                                                               uint2* __restrict__ out_s, unsigned long long* stats) {
     __shared__ RepackLds repack[4];
     RepackLds& L = repack[(threadIdx.x >> 6) & 3];

@@ -91,8 +91,12 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2  # 1 024 SIMDs, one 64-wide vector instruct
 
 
 def profile_json(name):
-    path = os.path.join(ROOT, "profiles", name)
-    return json.load(open(path)) if os.path.exists(path) else None
+    """The committed counter summary `name` of the newest round that has one (profiles/r03_<name>, else r02_<name>)."""
+    for rnd in ("r03_", "r02_"):
+        path = os.path.join(ROOT, "profiles", rnd + name)
+        if os.path.exists(path):
+            return json.load(open(path))
+    return None
 
 
 def count_frame(core, cam, width, height, outs):
@@ -167,7 +171,7 @@ def streaming_leg(rt, dev, steps, warmup):
     # What reaches HBM (hardware counters of the same command, committed): `frac` is THAT over the HBM peak. The
     # algorithmic figure stays beside it: neighbouring rays share cells, so most of those bytes are cache hits.
     out["algorithmic_GBps"] = achieved
-    t = profile_json("r02_streaming_traffic.json")
+    t = profile_json("streaming_traffic.json")
     if t and t.get("triangles") == n and abs(t.get("cell_size", cell) - cell) < 1e-3 and t.get("repack_candidates", 0) == repack:
         out["traffic"] = t["bytes_per_launch"]
         out["achieved"] = t["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
@@ -612,8 +616,8 @@ def main():
                              "40 B per candidate, 8 B per ray); fetched bytes are what the timed kernel requests from the memory "
                              "system; traffic is what reached HBM (hardware counters). Rates are per frame of the timed region "
                              "(launches overlap), not per launch.")}
-            t = profile_json("r02_headline_traffic.json") if WORKLOAD == "car1080" else None
-            v = profile_json("r02_headline_valu.json") if WORKLOAD == "car1080" else None
+            t = profile_json("headline_traffic.json") if WORKLOAD == "car1080" else None
+            v = profile_json("headline_valu.json") if WORKLOAD == "car1080" else None
             if t:
                 roof["traffic"] = t["bytes_per_launch"]
                 roof["hbm_traffic_frac"] = t["bytes_per_launch"] / frame_s / 1e9 / HBM_PEAK_GBS

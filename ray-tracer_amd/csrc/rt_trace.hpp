@@ -1123,8 +1123,20 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
             deal = MODE == 1 ? rounds * 130u + 50u < longest * 55u : rounds * 180u + 100u < longest * 55u;
         }
         if (!deal) {
-            if (n != 0) {  // this lane's own list, two records per trip, each loaded while the other is tested
-                auto test = [&](const float4& c0, const float4& c1, const float4& c2, uint32_t r) -> bool {
+            // One list shared by every lane that has one (rays that are still in the same cell: near the camera, or the
+            // whole way on scenes whose neighbouring rays stay together): the WAVE copies it into LDS once, all 64 lanes
+            // fetching a record each, and the lanes scan it from there in order - three load instructions per 64
+            // records instead of three per record. The words the dealing branch uses serve as the buffer.
+            const unsigned long long has = __builtin_amdgcn_ballot_w64(n != 0);
+            bool shared = false;
+            uint32_t r0 = 0, n0 = 0;
+            if (has != 0ull) {
+                const int first = __builtin_ctzll(has);
+                r0 = (uint32_t)__builtin_amdgcn_readlane((int)cell.x, first);
+                n0 = (uint32_t)__builtin_amdgcn_readlane((int)n, first);
+                shared = __builtin_amdgcn_ballot_w64(n != 0 && cell.x == r0 && n == n0) == has;
+            }
+            auto test = [&](const float4& c0, const float4& c1, const float4& c2, uint32_t r) -> bool {
                     if (__float_as_uint(c1.w) & arrival) return false;
                     const float t = moller_trumbore_pk<WGSL>(make_ray_pk(o, d), c0, c1, c2);
                     if (t > 0.0f && t < closest && __float_as_uint(c0.w) < REF_INVISIBLE) {
@@ -1140,7 +1152,27 @@ __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& r
                         return ANY;
                     }
                     return false;
-                };
+            };
+            if (shared) {
+                float4* stage = reinterpret_cast<float4*>(&L);
+                constexpr uint32_t PIECE = sizeof(RepackLds) / 48 < 64 ? sizeof(RepackLds) / 48 : 64;  // records per copy
+                bool done = n == 0;  // lanes without the list only help to copy it
+                for (uint32_t base = 0; base < n0; base += PIECE) {
+                    const uint32_t cnt = n0 - base < PIECE ? n0 - base : PIECE;
+                    if (lane < cnt) {
+                        stage[3 * lane] = buf_load16<0>(refs_d, r0 + base + lane);
+                        stage[3 * lane + 1] = buf_load16<16>(refs_d, r0 + base + lane);
+                        stage[3 * lane + 2] = buf_load16<32>(refs_d, r0 + base + lane);
+                        if (COUNT) ctr->staged_recs++;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (uint32_t k = 0; k < cnt && !done; ++k) done = test(stage[3 * k], stage[3 * k + 1], stage[3 * k + 2], r0 + base + k);
+                    __builtin_amdgcn_wave_barrier();  // the next piece, or the next step's dealing, overwrites the buffer
+                    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+                }
+            } else if (n != 0) {  // this lane's own list, two records per trip, each loaded while the other is tested
                 uint32_t r = cell.x;
                 const uint32_t r_end = r + n;
                 float4 a0 = buf_load16<0>(refs_d, r), a1 = buf_load16<16>(refs_d, r), a2 = buf_load16<32>(refs_d, r);

@@ -63,8 +63,8 @@ def test_rays_in_different_cells_equal_the_oracle(rt, ob, wgsl):
 def test_counting_build_of_the_dealing_kernel(rt):
     """collect_stats = 2 with repack_candidates on runs the counting build of k_trace_primary_repack: the records are
     the uncounted kernel's, rays and hits are the plain counting kernel's, and the fetch counters describe the dealing
-    kernel (nothing staged; no more reference records than the plain loop with its look-ahead asks for, no fewer cell
-    records than the plain loop behind the frame's block mask)."""
+    kernel (no more reference records than the plain loop with its look-ahead asks for, no fewer cell records than the
+    plain loop behind the frame's block mask)."""
     xyz9 = random_soup(20000, 5)
     on, off = pair(rt, rt.triangles_from_xyz9(xyz9), cell_size=4.0)
     try:
@@ -84,9 +84,8 @@ def test_counting_build_of_the_dealing_kernel(rt):
             for k in ("rays", "primary_hits", "shadow_rays", "shadow_hits"):
                 assert a[k] == b[k], (k, a[k], b[k])
             assert a["rays"] == w * h + int((p["id"] != rt.RT_MISS).sum())
-            assert a["ref_records_staged"] == 0
             assert a["cell_records_fetched"] >= b["cell_records_fetched"] > 0
-            assert 0 < a["ref_records_fetched"] <= b["ref_records_fetched"] + b["ref_records_staged"] * 64
+            assert 0 < a["ref_records_fetched"] + a["ref_records_staged"] <= b["ref_records_fetched"] + b["ref_records_staged"] * 64
     finally:
         on.close(), off.close()
 

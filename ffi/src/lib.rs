@@ -7,6 +7,8 @@ use std::ffi::{c_char, c_int, c_void, CStr};
 #[derive(Clone, Copy, Debug, Default, bytemuck::Pod, bytemuck::Zeroable)]
 pub struct RtHit { pub id: u32, pub t: f32 }
 pub const RT_MISS: u32 = 0xFFFF_FFFF;
+/// `RtShard::owner` entry of a tile nobody traces (rt_tile_flags, rt_assemble_frames_sky).
+pub const RT_OWNER_SKY: u32 = 0xFFFF_FFFF;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
@@ -74,6 +76,13 @@ extern "C" {
     pub fn rt_assemble_frames(ctx: *mut RtCtx, gathered: *const u8, pixel_format: u32, width: u32, height: u32, tile_w: u32,
                               tile_h: u32, n_ranks: u32, owner: *const u32, round: u32, n_frames: u32, rank_stride: usize,
                               frame_stride: usize, images: *mut u8) -> c_int;
+    /// flags: one byte per tile, 0 = the tile shows nothing but sky from this camera (nobody renders or sends it).
+    pub fn rt_tile_flags(ctx: *mut RtCtx, camera: *const c_void, width: u32, height: u32, tile_w: u32, tile_h: u32,
+                         flags: *mut u8) -> c_int;
+    /// rt_assemble_frames for owner tables with RT_OWNER_SKY entries: those tiles are written from cameras[frame].
+    pub fn rt_assemble_frames_sky(ctx: *mut RtCtx, gathered: *const u8, pixel_format: u32, width: u32, height: u32, tile_w: u32,
+                                  tile_h: u32, n_ranks: u32, owner: *const u32, round: u32, cameras: *const c_void, n_frames: u32,
+                                  rank_stride: usize, frame_stride: usize, images: *mut u8) -> c_int;
     pub fn rt_assemble_frames_rgba8(ctx: *mut RtCtx, gathered: *const u8, width: u32, height: u32, tile_w: u32, tile_h: u32,
                                     n_ranks: u32, n_frames: u32, rank_stride: usize, frame_stride: usize, images: *mut u8) -> c_int;
     pub fn rt_set_skin(ctx: *mut RtCtx, positions: *const f32, joints: *const u16, weights: *const f32, n_vertices: u32,

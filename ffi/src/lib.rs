@@ -90,6 +90,10 @@ extern "C" {
     pub fn rt_skin_vertices(ctx: *mut RtCtx, joint_matrices: *const f32, n_joints: u32) -> c_int;
     pub fn rt_read_vertices(ctx: *mut RtCtx, xyz9: *mut f32) -> c_int;
     pub fn rt_build_bvh(ctx: *mut RtCtx) -> c_int;
+    /// The same tree by the reference's recursion on one host thread (the GPU builder's checker).
+    pub fn rt_build_bvh_host(ctx: *mut RtCtx) -> c_int;
+    /// nodes: 8 f32 per node in pre-order; sizes from rt_get_bvh_stats. Any pointer may be null.
+    pub fn rt_read_bvh(ctx: *mut RtCtx, nodes: *mut f32, leaf_first: *mut u32, prims: *mut u32) -> c_int;
     pub fn rt_trace_rays_bvh(ctx: *mut RtCtx, origins: *const f32, dirs: *const f32, n: u32, out_t: *mut f32) -> c_int;
     pub fn rt_intersect_tri_pairs_watertight(ctx: *mut RtCtx, origins: *const f32, dirs: *const f32, n_rays: u32,
                                              v012: *const f32, n_prims: u32, out_t: *mut f32) -> c_int;

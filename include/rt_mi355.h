@@ -364,10 +364,20 @@ typedef struct rt_bvh_stats {
 } rt_bvh_stats;
 
 /* BVHNode::build over the scene's triangles (src/core/bvh.rs:44-232: binned SAH, 12 buckets, leaves of up
- * to 4), built on the host from the current vertices and uploaded; rebuilt by the caller after rt_set_scene,
- * rt_update_vertices or rt_skin_vertices. */
+ * to 4, the partition of :212-232 element for element), built on the GPU from the current vertices, level by level;
+ * the tree is the reference's node for node (same boxes, same leaves, same order of a leaf's primitives). Rebuilt by
+ * the caller after rt_set_scene, rt_update_vertices or rt_skin_vertices. */
 int rt_build_bvh(rt_ctx* ctx);
+/* The same tree built by the reference's recursion on the host (one thread) and uploaded: what rt_build_bvh is checked
+ * against node for node, and its timing baseline. */
+int rt_build_bvh_host(rt_ctx* ctx);
 int rt_get_bvh_stats(rt_ctx* ctx, rt_bvh_stats* stats);
+/* The tree as the traversal reads it (BVHNode flattened, src/core/bvh.rs:12-31): nodes = 8 floats per node in pre-order
+ * - min.xyz, the bits of the "skip" index (the node after this one's subtree), max.xyz, the bits of the leaf's primitive
+ * count (0: internal node; the left child is the next node, the right one follows the left subtree); leaf_first[node] =
+ * first entry of a leaf in prims; prims = triangle indices in leaf order. Host memory, sized from rt_get_bvh_stats
+ * (node_count, total_primitives); any pointer may be NULL. */
+int rt_read_bvh(rt_ctx* ctx, float* nodes, uint32_t* leaf_first, uint32_t* prims);
 /* traverse_bvh_triangles of the reference's benchmark (examples/massive_benchmark.rs:226-270,311-320) for a list
  * of rays: both children of every node whose box the ray meets, Moller-Trumbore in the leaves, smallest t.
  * out_t[i] = t, or -1 when nothing is hit (the example's None). origins/dirs/out_t all host or all device. */

@@ -141,6 +141,8 @@ PROTOTYPES = {
     "rt_broadcast_scene": (_I, [_VP, _I, _VP, _U32, _VP, _U32]),
     "rt_gather_frames": (_I, [_VP, _I, _VP, C.c_size_t, _VP]),
     "rt_build_bvh": (_I, [_VP]),
+    "rt_build_bvh_host": (_I, [_VP]),
+    "rt_read_bvh": (_I, [_VP, _VP, _VP, _VP]),
     "rt_get_bvh_stats": (_I, [_VP, C.POINTER(RtBvhStats)]),
     "rt_trace_rays_bvh": (_I, [_VP, _VP, _VP, _U32, _VP]),
     "rt_set_skin": (_I, [_VP, _VP, _VP, _VP, _U32, _VP, _U32]),

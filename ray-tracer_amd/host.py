@@ -279,12 +279,23 @@ class TraceCore:
 
     # ---- tracing
     # ---- bounding volume hierarchy
-    def build_bvh(self):
-        """Returns BVHStats as a dict."""
-        self._ck(self._L.rt_build_bvh(self._h))
+    def build_bvh(self, on_host=False):
+        """rt_build_bvh (on the GPU), or rt_build_bvh_host: the same tree by the reference's recursion on one host
+        thread. Returns BVHStats as a dict."""
+        self._ck((self._L.rt_build_bvh_host if on_host else self._L.rt_build_bvh)(self._h))
         st = RtBvhStats()
         self._ck(self._L.rt_get_bvh_stats(self._h, C.byref(st)))
         return {k: int(getattr(st, k)) for k, _ in st._fields_}
+
+    def read_bvh(self):
+        """rt_read_bvh: (nodes float32 (n_nodes, 8), leaf_first uint32 (n_nodes,), prims uint32 (n_prims,))."""
+        st = RtBvhStats()
+        self._ck(self._L.rt_get_bvh_stats(self._h, C.byref(st)))
+        nodes = np.empty((int(st.node_count), 8), np.float32)
+        leaf_first = np.empty(int(st.node_count), np.uint32)
+        prims = np.empty(int(st.total_primitives), np.uint32)
+        self._ck(self._L.rt_read_bvh(self._h, _ptr(nodes), _ptr(leaf_first), _ptr(prims)))
+        return nodes, leaf_first, prims
 
     def trace_rays_bvh(self, origins, dirs, out=None, n=None):
         """Closest t per ray (-1 = none). numpy in -> numpy out; torch CUDA tensors throughout with `out`."""

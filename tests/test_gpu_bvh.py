@@ -70,3 +70,50 @@ def test_car_frame_rays_and_degenerate_directions(core, ob, rt, car_xyz9):
     core.update_vertices(car_xyz9 + np.float32(1.0))
     with pytest.raises(rt.RtError):
         core.trace_rays_bvh(o, d)
+
+
+def same_tree(core, what):
+    """rt_build_bvh (GPU, level by level) against rt_build_bvh_host (the reference's recursion): node for node."""
+    st_gpu = core.build_bvh()
+    nodes, leaf_first, prims = core.read_bvh()
+    st_host = core.build_bvh(on_host=True)
+    hn, hl, hp = core.read_bvh()
+    assert st_gpu == st_host, (what, st_gpu, st_host)
+    assert np.array_equal(prims, hp), f"{what}: primitive order differs at {np.flatnonzero(prims != hp)[:5]}"
+    assert np.array_equal(leaf_first, hl), what
+    bad = np.flatnonzero((nodes.view(np.uint32) != hn.view(np.uint32)).any(axis=1))
+    assert bad.size == 0, f"{what}: {bad.size} of {len(nodes)} nodes differ, first {bad[:3]}: {nodes[bad[:3]]} vs {hn[bad[:3]]}"
+    return st_gpu
+
+
+def test_gpu_builder_makes_the_reference_tree(core, ob, rt, car_xyz9, phoenix_xyz9):
+    rng = np.random.default_rng(7)
+    # sizes around the leaf limit, the generator's scenes (30 000: every triangle three times, so partitions fail and
+    # leaves grow past four), both bundled models, random soups with degenerate and repeated triangles
+    for n in (1, 2, 4, 5, 6, 9, 17, 100):
+        core.set_scene(None, ob.generate_test_triangles(n))
+        same_tree(core, f"{n} generator triangles")
+    for n in (1000, 30000):
+        core.set_scene(None, ob.generate_test_triangles(n))
+        st = same_tree(core, f"{n} generator triangles")
+        assert st["total_primitives"] == n
+    for name, xyz9 in (("static model", car_xyz9), ("animated model", phoenix_xyz9)):
+        core.set_scene(None, rt.triangles_from_xyz9(xyz9))
+        st = same_tree(core, name)
+        assert st["node_count"] > len(xyz9) // 4
+    for trial in range(6):
+        n = int(rng.integers(50, 20000))
+        c = rng.uniform(-50, 50, (n, 1, 3)).astype(np.float32)
+        v = (c + rng.normal(0, [0.01, 1.0, 30.0][trial % 3], (n, 3, 3)).astype(np.float32)).astype(np.float32)
+        v[rng.integers(0, n, n // 20)] = v[rng.integers(0, n, n // 20)]      # exact copies
+        k = rng.integers(0, n, n // 25)
+        v[k, 1] = v[k, 0]                                                    # degenerate: two equal vertices
+        if trial % 2:
+            v[:, :, trial % 3] = np.float32(3.0)                             # flat along one axis: that axis is never split
+        core.set_scene(None, rt.triangles_from_xyz9(v.reshape(n, 9)))
+        same_tree(core, f"random soup {trial} ({n} triangles)")
+    # all triangles equal: the root's partition fails, one leaf holds everything, in the partition's order
+    one = np.tile(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32), (37, 1))
+    core.set_scene(None, rt.triangles_from_xyz9(one))
+    st = same_tree(core, "37 copies of one triangle")
+    assert st["node_count"] == 1 and st["leaf_count"] == 1

@@ -2000,6 +2000,9 @@ extern "C" int rt_render_frames(rt_ctx* c, const CameraUniform* cams, uint32_t n
     } else if (wide_grid(s)) {
         if (wgsl) hipLaunchKernelGGL((k_render<true, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
         else hipLaunchKernelGGL((k_render<false, true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+    } else if (c->tex_mode != 0 && o.max_bounces == 1 && !has_boxes) {  // textured, direct lighting only: no bounce loop to carry state through
+        if (wgsl) hipLaunchKernelGGL((k_render<true, false, true, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
+        else hipLaunchKernelGGL((k_render<false, false, true, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
     } else if (c->tex_mode != 0) {  // materials name textures: the general kernel with the material path
         if (wgsl && has_boxes) hipLaunchKernelGGL((k_render<true, true, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);
         else if (wgsl) hipLaunchKernelGGL((k_render<true, false, true>), grid, dim3(256), 0, c->stream, s, fs, m, sh, out, st, rmask, rwords);

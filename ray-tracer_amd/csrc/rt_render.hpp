@@ -47,10 +47,13 @@ __device__ inline bool near_grid_boundary(const DevScene& s, V3 pos, float thres
 #ifndef RT_RENDER_WAVES
 #define RT_RENDER_WAVES 1
 #endif
+#ifndef RT_RENDER_TEX_SINGLE_WAVES
+#define RT_RENDER_TEX_SINGLE_WAVES 6  // waves per SIMD the textured single-bounce instantiation is held to
+#endif
 // SINGLE: max_bounces == 1 (direct lighting only): no bounce loop, so the ray origin stays the camera position in
 // scalar registers and nothing is carried from one traversal to the next.
 template <bool WGSL, bool BOXES, bool TEX = false, bool WIDE = false, bool SINGLE = false>
-__global__ __launch_bounds__(256, SINGLE ? 8 : RT_RENDER_WAVES) void k_render(DevScene s, DevFrames fs, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(256, SINGLE ? (TEX ? RT_RENDER_TEX_SINGLE_WAVES : 8) : RT_RENDER_WAVES) void k_render(DevScene s, DevFrames fs, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
                                                 unsigned long long* stats, const uint32_t* __restrict__ cull_masks, uint32_t cull_words) {
     const DevFrame& f = fs.f[blockIdx.y];
     const float show_grid = fs.show_grid[blockIdx.y];

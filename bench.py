@@ -9,8 +9,8 @@ hit, all inside one kernel launch, with scene, grid and output buffers resident 
 with a two-image swap chain, consecutive frames go to two streams with their own output buffers (two frames in
 flight): a frame's last waves - a few pixel blocks over the model's densest cells, one long dependent chain
 each - then overlap the next frame's bulk instead of leaving the GPU idle. At N > 1
-the SAME frame is cut into 32x32 tiles dealt to the ranks (rank 0, which also gathers and assembles, gets 5 of every 61
-at N = 8 where the others get 8), each rank shades its tiles (same
+the SAME frame is cut into 32x32 tiles dealt to the ranks (rank 0, which also gathers and assembles, gets 3 of every 59
+at N = 8 where the others get 8; tiles that show nothing but sky are neither rendered nor sent), each rank shades its tiles (same
 primary + shadow rays) and the RGBA8 framebuffer is gathered on rank 0 by RCCL (total work fixed: strong
 scaling; 3 bytes per pixel cross the links - the picture without its constant alpha byte - instead of 16 for hit
 records). A rank's share of one 1080p frame is
@@ -65,7 +65,11 @@ FRAMES_IN_FLIGHT = int(os.environ.get("RT_BENCH_IN_FLIGHT", "3"))
 # time, so a group must hold enough frames for one collective's host cost (a few hundred us through Python) to hide
 # behind its rendering.
 GROUP = int(os.environ.get("RT_BENCH_GROUP", "4" if WORKLOAD == "massive8k" else "32"))
-GROUPS_IN_FLIGHT = int(os.environ.get("RT_BENCH_GROUPS_IN_FLIGHT", "2"))
+# Groups in flight: the gathering rank's stream holds render, receive and assemble of a group one after the other, and
+# each waits for the last waves of the one before; measured with one GPU playing rank 0 of 8 (tools/group_cost.py,
+# RT_INFLIGHT): 12.2 us per frame with two groups in flight, 10.1 with three, 9.3 with four (the other ranks: 8.2-9.6
+# whatever the number). Three: a process has four hardware queues and the collective wants one.
+GROUPS_IN_FLIGHT = int(os.environ.get("RT_BENCH_GROUPS_IN_FLIGHT", "3"))
 # Tiles that show nothing but sky from the frame's camera are neither rendered nor sent at N > 1: which they are follows
 # from the camera alone, and rank 0's assemble kernel writes them (byte-identical pictures; RT_BENCH_SPARSE=0: every tile
 # travels).
@@ -457,7 +461,10 @@ def main():
         # rank 0 also receives and assembles every frame, so it renders a smaller share: 5 tiles of every 61 at
         # N = 8 where the others render 8 (RT_BENCH_WEIGHTS=equal, or a comma-separated list, for experiments)
         wenv = os.environ.get("RT_BENCH_WEIGHTS", "")
-        weights = None if wenv == "equal" else [int(k) for k in wenv.split(",")] if wenv else sharding.gatherer_weights(world)
+        # with the sky tiles left out a rank's share costs less and rank 0's assemble (the whole frame, sky included) as much
+        # as before: 3 tiles of every 59 at N = 8 (11 of 59 at N = 4, 27 of 59 at N = 2) level the ranks, measured as above
+        weights = (None if wenv == "equal" else [int(k) for k in wenv.split(",")] if wenv
+                   else sharding.gatherer_weights(world, lag=5 if SPARSE else 3))
         sh = sharding.FrameSharder(core, WIDTH, HEIGHT, TILE, TILE, rank, world, dev, shadow=True, mode="rgba",
                                    frames_in_flight=1, max_bounces=1, collective=True, weights=weights, host_gather=rehearsal)
         sh.enable_groups(GROUP, GROUPS_IN_FLIGHT, rgb8=os.environ.get("RT_BENCH_WIRE", "rgb") == "rgb")  # the constant alpha byte stays at home

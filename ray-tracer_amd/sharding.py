@@ -288,11 +288,23 @@ class FrameSharder:
 
     def prepare_cameras(self, cams):
         """Classifies the tiles of every camera not seen before (one small synchronous GPU pass each, identical on every
-        rank). Call it ahead of the frames - at scene load for a fixed camera or a recorded path."""
+        rank). Call it ahead of the frames - at scene load for a fixed camera or a recorded path - on EVERY rank with the
+        same cameras: with more than one rank the ranks compare what they found (one small all-reduce per new camera),
+        and a camera whose tiles they do not agree on is left unannounced (its groups travel whole), because ranks that
+        dealt the tiles differently would wait for each other for ever."""
         for cam in cams:
             key = bytes(cam)
-            if key not in self._tile_flags:
-                self._tile_flags[key] = np.asarray(self.core.tile_flags(cam, self.width, self.height, self.tile_w, self.tile_h), np.uint8) != 0
+            if key in self._tile_flags:
+                continue
+            flags = np.asarray(self.core.tile_flags(cam, self.width, self.height, self.tile_w, self.tile_h), np.uint8) != 0
+            if self.world > 1 and self.collective and dist.is_available() and dist.is_initialized():
+                digest = int(np.flatnonzero(flags).astype(np.int64).sum() * 31 + int(flags.sum())) % (1 << 40)
+                where = self.device if dist.get_backend() == "nccl" else "cpu"
+                both = torch.tensor([digest, -digest], dtype=torch.int64, device=where)
+                dist.all_reduce(both, op=dist.ReduceOp.MAX)
+                if int(both[0]) != -int(both[1]):  # max(digest) != min(digest)
+                    continue
+            self._tile_flags[key] = flags
 
     def _sparse_plan(self, cams):
         """Who renders what for this group, or None when one of its cameras has not been announced. A tile is left out

@@ -1058,7 +1058,10 @@ __device__ inline uint32_t wave_running_max(uint32_t x) {
 // TRIP: what a trip of the plain scan is taken to cost against 130 for a round of 64 dealt pairs (MODE 1). 55 for the
 // rays of a frame; rays in no order (k_trace_rays_repack) deal more readily, 75: 4 M random rays 2.55 -> 2.25 ms, where
 // the same setting costs the frames of the bundled animated model a fifth (155 -> 191 us) and the streaming frame 1 %.
-template <bool WGSL, bool ANY, int MODE = 1, bool TEX = false, bool COUNT = false, unsigned TRIP = 55u>
+#ifndef RT_DEAL_TRIP_FRAMES
+#define RT_DEAL_TRIP_FRAMES 55u
+#endif
+template <bool WGSL, bool ANY, int MODE = 1, bool TEX = false, bool COUNT = false, unsigned TRIP = RT_DEAL_TRIP_FRAMES>
 __device__ inline bool trace_ray_repack(const DevScene& s, V3 o, const RayDir& rd, bool active, HitRec& out, RepackLds& L,
                                         Counters* ctr = nullptr) {
     const uint32_t lane = threadIdx.x & 63;

@@ -191,8 +191,11 @@ __global__ __launch_bounds__(256, SINGLE ? (TEX ? RT_RENDER_TEX_SINGLE_WAVES : 8
 // therefore the same in every lane of the wave; `going` says whether this lane's path is still followed. Per lane the
 // arithmetic is k_render's, operation for operation.
 // ALPHA: some material's alpha is a texture's, so the traversals sample it per hit (trace_ray<TEX>).
+#ifndef RT_RENDER_DEAL_WAVES
+#define RT_RENDER_DEAL_WAVES 4  // waves per SIMD the kernel is held to
+#endif
 template <bool WGSL, bool TEX, bool ALPHA = false>
-__global__ __launch_bounds__(256, 4) void k_render_deal(DevScene s, DevFrames fs, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
+__global__ __launch_bounds__(256, RT_RENDER_DEAL_WAVES) void k_render_deal(DevScene s, DevFrames fs, ShardMap m, DevShade sh, uint32_t* __restrict__ out,
                                                      const uint32_t* __restrict__ cull_masks, uint32_t cull_words) {
     __shared__ RepackLds repack[4];
     const DevFrame& f = fs.f[blockIdx.y];

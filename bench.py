@@ -524,11 +524,14 @@ def main():
     if not multi:
         for (_, e1), st in zip(ev, streams):
             e1.record(st)
-    sync()
-    torch.cuda.synchronize()
+    if multi:
+        sync()  # starts what is left of the last group, then waits for this rank's streams
+    torch.cuda.synchronize()  # the whole device: every stream the steps were queued on
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if not multi:
+        sync()  # nothing left to wait for: the library notes that no frame is in flight any more
     if not multi:
         # average time one launch occupies its stream; with several frames in flight as many launches overlap, so
         # this is about that many times the time per frame

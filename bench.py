@@ -266,8 +266,9 @@ def cpu_baseline(xyz9, width, height):
     pairs_ms = (time.perf_counter() - t0) / 20 * 1e3
     return {"value": len(ro) / mean / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "criterion_100_rays_x_10000_aabbs_ms": pairs_ms,
-            "sample": f"every {stride}th of the frame's {len(p) + int(hit.sum())} primary+shadow rays "
-                      f"({len(ro)} rays), BVH build + both-children traversal, mean of 5 passes",
+            "sample": (f"all of the frame's {len(ro)} primary+shadow rays" if stride == 1 else
+                       f"one in {stride} of the frame's {len(p) + int(hit.sum())} primary+shadow rays ({len(ro)} rays)")
+                      + ", BVH build + both-children traversal, mean of 5 passes",
             "min_ms": min(times) * 1e3, "max_ms": max(times) * 1e3,
             "single_thread_Mrays": n1 / one / 1e6, "grid_traversal_port_Mrays": len(ro) / dda / 1e6}
 

@@ -39,6 +39,25 @@ def _timed(core, fn, reps):
     return core.timer_end() / reps  # ms
 
 
+def _timed_in_flight(core, frame, streams, reps):
+    """ms per frame with len(streams) frames in flight, as the headline leg runs them: frame k goes to stream k mod n
+    (and to output buffers of its own); the host's clock around `reps` frames between two waits for all streams."""
+    for k in range(len(streams)):
+        core.set_stream(streams[k].cuda_stream)
+        frame(k)
+    core.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(reps):
+        core.set_stream(streams[k % len(streams)].cuda_stream)
+        frame(k % len(streams))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / reps
+    core.sync()
+    core.set_stream(None)
+    return ms
+
+
 def _count(core, cam, w, h, outs):
     """The reference algorithm's work on one frame (cells visited, candidates tested), by the counting kernel."""
     core.set_collect_stats(1)
@@ -103,7 +122,10 @@ def criterion(rt, dev, repeats=5):
 def massive(rt, dev, width, height, sizes, dup_modes, repeats=None, name="massive4k"):
     from ray_tracer_amd import workloads as wl
     cam = rt.Camera((0, 0, 150), math.pi, 0.0).to_uniform(0.0, float(height))
-    outs = (torch.empty((width * height, 2), dtype=torch.int32, device=dev), torch.empty((width * height, 2), dtype=torch.int32, device=dev))
+    flight = [(torch.empty((width * height, 2), dtype=torch.int32, device=dev), torch.empty((width * height, 2), dtype=torch.int32, device=dev))
+              for _ in range(3)]
+    outs = flight[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
     legs = []
     for n in sizes:
         tris = wl.generate_test_triangles(n)
@@ -117,12 +139,15 @@ def massive(rt, dev, width, height, sizes, dup_modes, repeats=None, name="massiv
             st = _count(core, cam, width, height, outs)
             heavy = not skip and n >= 1000000  # tens of milliseconds a frame: one timed launch is enough
             reps = repeats or (1 if heavy else 10)
-            ms = _timed(core, lambda: core.trace_primary(cam, width, height, shadow=True, out_primary=outs[0], out_shadow=outs[1]), reps)
+            one = _timed(core, lambda: core.trace_primary(cam, width, height, shadow=True, out_primary=outs[0], out_shadow=outs[1]), reps)
+            ms = min(one, _timed_in_flight(
+                core, lambda k: core.trace_primary(cam, width, height, shadow=True, out_primary=flight[k][0], out_shadow=flight[k][1]),
+                streams, 3 * reps))
             leg = {"config": f"configs[{2 if height == 2160 else 4}] massive_benchmark scene, {n} triangles, {width}x{height} primary + shadow, "
                              f"reference grid (cell 16), duplicate triangles {'left out' if skip else 'tested'}",
                    "kernel": "k_trace_primary_lean<shadow>", "triangles": n, "skip_duplicate_triangles": skip,
                    "grid": list(meta.fine_dims), "cell_refs": n_refs, "trace_refs": core.trace_refs(), "build_ms_wall_first": build_ms,
-                   "ms": ms, "rays": st["rays"], "primary_hits": st["primary_hits"], "Grays_per_s": st["rays"] / ms / 1e6,
+                   "ms": ms, "ms_one_frame_at_a_time": one, "frames_in_flight": 1 if ms == one else 3, "rays": st["rays"], "primary_hits": st["primary_hits"], "Grays_per_s": st["rays"] / ms / 1e6,
                    "tri_tests_reference": st["tri_tests"], "Gtests_per_s_reference": st["tri_tests"] / ms / 1e6}
             leg.update(_roof(f"{name}_{n}_{'skip' if skip else 'all'}", ms, _algorithmic_bytes(st)))
             legs.append(leg)

@@ -162,7 +162,7 @@ def animated(rt, dev, frames=60):
     mats = [torch.from_numpy(np.ascontiguousarray(model.joint_matrices(model.duration * f / frames), np.float32)).to(dev) for f in range(frames)]
     cam = rt.Camera((-300, 250, 600), 2.7, -0.2).to_uniform(0.0, float(h))
     legs = []
-    for n_ctx, heavy in ((1, 0), (2, 0), (2, 64)):
+    for n_ctx, heavy in ((1, 0), (2, 0), (2, 64), (3, 0), (3, 64)):  # four contexts are slower again (0.23 ms: a process has four hardware queues)
         cores = []
         for _ in range(n_ctx):
             c = rt.TraceCore(dev.index, rt.default_params(heavy_block_threshold=heavy))

@@ -95,3 +95,55 @@ def test_rebuild_paths_agree_for_modes_caps_and_boxes(core, ob, rt, mode, cell, 
     core.update_vertices(rotated(xyz, 60))
     core.build_grid(cell_size=cell * 0.5, max_per_cell=cap, mode=mode)
     assert core.build_path() == 0
+
+
+def test_contexts_driven_by_a_thread_each_give_the_same_frames(ob, rt, phoenix_xyz9):
+    """A renderer that keeps several frames of an animation in flight gives every context a host thread of its own (a
+    rebuild ends with a small read-back its thread waits for; the other threads go on launching). Three contexts, three
+    threads, frames dealt in turn: every frame's records equal those one context makes alone, which equal the oracle's
+    on the frames compared with it."""
+    import threading
+    n_ctx, frames, w, h = 3, 18, 320, 180
+    cam = ob.camera_to_uniform((-300, 250, 600), 2.7, -0.2, 0.0, float(h))
+    moved = [rotated(phoenix_xyz9, 5 * f + 1) for f in range(frames)]
+    alone = rt.TraceCore(0)
+    alone.set_scene(None, ob.triangles_from_xyz9(phoenix_xyz9))
+    alone.build_grid()
+    want = []
+    for f in range(frames):
+        alone.update_vertices(moved[f])
+        alone.build_grid()
+        want.append(alone.trace_primary(cam, w, h))
+    for f in (0, 7, 17):
+        scene = ob.Scene(None, ob.triangles_from_xyz9(moved[f]))
+        op, os_, _ = ob.trace_primary(scene, cam, w, h)
+        assert_hits_equal(want[f][0], op, f"frame {f} primary, one context")
+        assert_hits_equal(want[f][1], os_, f"frame {f} shadow, one context")
+    alone.close()
+    cores = [rt.TraceCore(0) for _ in range(n_ctx)]
+    for c in cores:
+        c.set_scene(None, ob.triangles_from_xyz9(phoenix_xyz9))
+        c.build_grid()
+    got, errors = [None] * frames, []
+
+    def frames_of(k):
+        try:
+            for f in range(k, frames, n_ctx):
+                cores[k].update_vertices(moved[f])
+                cores[k].build_grid()
+                got[f] = cores[k].trace_primary(cam, w, h)
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(e)))
+
+    for round_no in range(3):  # the same frames three times over: threads meet in a different order every time
+        workers = [threading.Thread(target=frames_of, args=(k,)) for k in range(n_ctx)]
+        for t in workers:
+            t.start()
+        for t in workers:
+            t.join()
+        assert not errors, errors
+        for f in range(frames):
+            assert_hits_equal(got[f][0], want[f][0], f"round {round_no} frame {f} primary")
+            assert_hits_equal(got[f][1], want[f][1], f"round {round_no} frame {f} shadow")
+    for c in cores:
+        c.close()

@@ -162,7 +162,9 @@ def animated(rt, dev, frames=60):
     mats = [torch.from_numpy(np.ascontiguousarray(model.joint_matrices(model.duration * f / frames), np.float32)).to(dev) for f in range(frames)]
     cam = rt.Camera((-300, 250, 600), 2.7, -0.2).to_uniform(0.0, float(h))
     legs = []
-    for n_ctx, heavy in ((1, 0), (2, 0), (2, 64), (3, 0), (3, 64)):  # four contexts are slower again (0.23 ms: a process has four hardware queues)
+    # four contexts are slower again (0.23 ms: a process has four hardware queues). threads: one host thread per context
+    # (a rebuild ends with a 56-byte read-back the host waits for; with a thread each, the other contexts' launches go on)
+    for n_ctx, heavy, threads in ((1, 0, False), (2, 0, False), (2, 64, False), (3, 0, False), (3, 64, False), (3, 0, True), (3, 64, True)):
         cores = []
         for _ in range(n_ctx):
             c = rt.TraceCore(dev.index, rt.default_params(heavy_block_threshold=heavy))
@@ -172,12 +174,27 @@ def animated(rt, dev, frames=60):
         outs = [(torch.empty((w * h, 2), dtype=torch.int32, device=dev), torch.empty((w * h, 2), dtype=torch.int32, device=dev))
                 for _ in range(n_ctx)]
 
-        def run():
-            for f, jm in enumerate(mats):
-                c, (p, s) = cores[f % n_ctx], outs[f % n_ctx]
-                c.skin_vertices(jm)
+        def frames_of(k, step):
+            c, (p, s) = cores[k], outs[k]
+            for f in range(k, frames, step):
+                c.skin_vertices(mats[f])
                 c.build_grid()
                 c.trace_primary(cam, w, h, shadow=True, out_primary=p, out_shadow=s)
+
+        def run():
+            if threads:
+                import threading
+                workers = [threading.Thread(target=frames_of, args=(k, n_ctx)) for k in range(n_ctx)]
+                for t in workers:
+                    t.start()
+                for t in workers:
+                    t.join()
+            else:
+                for f, jm in enumerate(mats):
+                    c, (p, s) = cores[f % n_ctx], outs[f % n_ctx]
+                    c.skin_vertices(jm)
+                    c.build_grid()
+                    c.trace_primary(cam, w, h, shadow=True, out_primary=p, out_shadow=s)
             torch.cuda.synchronize()
 
         run()  # the first build of a scene takes the general path; the timed frames rebuild
@@ -186,10 +203,10 @@ def animated(rt, dev, frames=60):
         frame_ms = (time.perf_counter() - t0) * 1e3 / frames
         rays = w * h + int((outs[(frames - 1) % n_ctx][0][:, 0] != -1).sum())
         leg = {"config": "configs[3] bundled animated model (4 064 triangles, 89 joints), skinning + grid rebuild + 1920x1080 primary + shadow "
-                         f"every frame, {n_ctx} context{'s used alternately' if n_ctx > 1 else ''}"
+                         f"every frame, {n_ctx} context{'s used alternately' if n_ctx > 1 else ''}{', a host thread each' if threads else ''}"
                          + (f", plan of expensive blocks (heavy_block_threshold {heavy})" if heavy else ""),
                "kernel": "k_skin + binning kernels + " + ("k_trace_primary_planned<shadow>" if heavy else "k_trace_primary_lean<shadow>"),
-               "contexts": n_ctx, "heavy_block_threshold": heavy, "frames": frames, "frame_ms_wall": frame_ms, "rays_last_frame": rays,
+               "contexts": n_ctx, "host_threads": n_ctx if threads else 1, "heavy_block_threshold": heavy, "frames": frames, "frame_ms_wall": frame_ms, "rays_last_frame": rays,
                "Grays_per_s_with_skinning_and_rebuild": rays / frame_ms / 1e6, "bound": "latency",
                "note": "one frame is a chain of about a dozen small launches and a trace whose longest waves are 100 us dependent "
                        "chains: nothing in it is near a throughput roof"}

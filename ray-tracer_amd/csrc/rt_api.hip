@@ -1118,6 +1118,7 @@ extern "C" void rt_destroy(rt_ctx* c) {
         (void)hipEventDestroy(c->ev_scratch);
     }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->fast_landing) (void)hipHostFree(c->fast_landing);
     delete c;
 }
 
@@ -1150,7 +1151,8 @@ extern "C" int rt_sync(rt_ctx* c) {
         RT_HIP(c, hipDeviceSynchronize());
         c->other_streams_busy = false;
     } else {
-        RT_HIP(c, hipStreamSynchronize(c->stream));
+        RT_HIP(c, wait_short(c->stream));  // a frame is a hundred microseconds: polled first, the driver's sleep after that
+        (void)hipGetLastError();
     }
     c->traced_on.clear();  // nothing is in flight any more: the next frame is a lone one until others join it
     c->scratch_busy = false;

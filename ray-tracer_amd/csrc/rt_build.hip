@@ -797,9 +797,12 @@ static int build_grid_fast(rt_ctx* c, float cell_size, uint32_t max_per_cell, in
                        (const uint32_t*)final_start, c->params.max_objects_per_cell, trace_cap, c->tri_mat.as<uint32_t>(),
                        c->materials.as<float4>(), c->n_materials, c->cells.as<uint2>(), c->refs.as<float4>());
     RT_HIP(c, hipGetLastError());
-    FastMeta h;
-    RT_HIP(c, hipMemcpyAsync(&h, meta, sizeof(h), hipMemcpyDeviceToHost, st));
-    RT_HIP(c, hipStreamSynchronize(st));
+    static_assert(sizeof(FastMeta) <= 256, "the landing buffer holds one FastMeta");
+    if (!c->fast_landing) RT_HIP(c, hipHostMalloc(&c->fast_landing, 256, hipHostMallocDefault));
+    RT_HIP(c, hipMemcpyAsync(c->fast_landing, meta, sizeof(FastMeta), hipMemcpyDeviceToHost, st));
+    RT_HIP(c, wait_short(st));
+    (void)hipGetLastError();
+    const FastMeta h = *static_cast<const FastMeta*>(c->fast_landing);
     if (getenv("RT_DEBUG_BUILD"))
         fprintf(stderr, "fast build: overflow %u dims %u %u %u cells %u pairs %llu refs %u | lim cells %u bordered %u pairs %u refs %u\n",
                 h.overflow, h.gx, h.gy, h.gz, h.n_cells, h.n_pairs, h.n_refs, lim.cells, lim.bordered, lim.pairs, lim.refs);

@@ -162,6 +162,7 @@ struct rt_ctx {
     uint32_t fast_total = 0, fast_pairs = 0, fast_bordered = 0;
     float fast_cell = 0.0f;
     rt::DevBuf fast_meta, fast_scan;
+    void* fast_landing = nullptr;  // 256 bytes of pinned host memory: where the rebuild's sizes arrive
 
     // binning scratch
     rt::DevBuf b_partial, b_counts, b_tmp_start, b_cursor, b_tmp_ids, b_tmp_sorted, b_tmp_cell, b_scan_tmp, b_flags,
@@ -200,6 +201,17 @@ inline int fail(rt_ctx* c, int code, const char* fmt, ...) {
             return rt::fail((c), RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
                             __FILE__, __LINE__);                                                     \
     } while (0)
+
+// Waits for a stream whose remaining work is short (a few small kernels and a copy of some bytes): polls it for a
+// few hundred microseconds before going to sleep in the driver, whose wake-up costs more than such a wait is long.
+inline hipError_t wait_short(hipStream_t st) {
+    for (int k = 0; k < 600; ++k) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
+    (void)hipGetLastError();  // "not ready" is no error to report later
+    return hipStreamSynchronize(st);
+}
 
 // true when p points to device-accessible memory allocated through HIP
 inline bool is_device_ptr(const void* p) {

@@ -164,7 +164,7 @@ def animated(rt, dev, frames=60):
     legs = []
     # four contexts are slower again (0.23 ms: a process has four hardware queues). threads: one host thread per context
     # (a rebuild ends with a 56-byte read-back the host waits for; with a thread each, the other contexts' launches go on)
-    for n_ctx, heavy, threads in ((1, 0, False), (2, 0, False), (2, 64, False), (3, 0, False), (3, 64, False), (3, 0, True), (3, 64, True)):
+    for n_ctx, heavy, threads in ((1, 0, False), (1, 64, False), (2, 0, False), (2, 64, False), (3, 0, False), (3, 64, False), (3, 0, True), (3, 64, True)):
         cores = []
         for _ in range(n_ctx):
             c = rt.TraceCore(dev.index, rt.default_params(heavy_block_threshold=heavy))

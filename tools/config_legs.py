@@ -155,16 +155,24 @@ def massive(rt, dev, width, height, sizes, dup_modes, repeats=None, name="massiv
     return legs
 
 
-def animated(rt, dev, frames=60):
+def animated(rt, dev, frames=int(os.environ.get("RT_ANIM_FRAMES", "200"))):
+    """The bundled animated model's clip (3.33 s) played at 60 frames per second: 200 poses, each skinned, rebuilt and
+    traced. (The plan of expensive blocks follows the previous frame: stepping through the clip in 60 poses instead - 18
+    frames per second - moves the wings by more than the plan tolerates, 0.26 instead of 0.22 ms per frame in one context.)"""
     from ray_tracer_amd.animation import SkinnedModel
     w, h = 1920, 1080
     model = SkinnedModel(os.path.join(ROOT, "tests", "golden", "phoenix_skin.npz"))
     mats = [torch.from_numpy(np.ascontiguousarray(model.joint_matrices(model.duration * f / frames), np.float32)).to(dev) for f in range(frames)]
     cam = rt.Camera((-300, 250, 600), 2.7, -0.2).to_uniform(0.0, float(h))
+    if os.environ.get("RT_ANIM_STATIC") == "1":  # development: the same pose every frame (what the plan gains without motion)
+        mats = [mats[7]] * frames
     legs = []
     # four contexts are slower again (0.23 ms: a process has four hardware queues). threads: one host thread per context
     # (a rebuild ends with a 56-byte read-back the host waits for; with a thread each, the other contexts' launches go on)
     for n_ctx, heavy, threads in ((1, 0, False), (1, 64, False), (2, 0, False), (2, 64, False), (3, 0, False), (3, 64, False), (3, 0, True), (3, 64, True)):
+        only = os.environ.get("RT_ANIM_ONLY")  # development: one leg, e.g. "1,64,0" (contexts, threshold, threads)
+        if only and tuple(int(v) for v in only.split(",")) != (n_ctx, heavy, int(threads)):
+            continue
         cores = []
         for _ in range(n_ctx):
             c = rt.TraceCore(dev.index, rt.default_params(heavy_block_threshold=heavy))
@@ -203,7 +211,7 @@ def animated(rt, dev, frames=60):
         frame_ms = (time.perf_counter() - t0) * 1e3 / frames
         rays = w * h + int((outs[(frames - 1) % n_ctx][0][:, 0] != -1).sum())
         leg = {"config": "configs[3] bundled animated model (4 064 triangles, 89 joints), skinning + grid rebuild + 1920x1080 primary + shadow "
-                         f"every frame, {n_ctx} context{'s used alternately' if n_ctx > 1 else ''}{', a host thread each' if threads else ''}"
+                         f"every frame of its clip at 60 frames per second, {n_ctx} context{'s used alternately' if n_ctx > 1 else ''}{', a host thread each' if threads else ''}"
                          + (f", plan of expensive blocks (heavy_block_threshold {heavy})" if heavy else ""),
                "kernel": "k_skin + binning kernels + " + ("k_trace_primary_planned<shadow>" if heavy else "k_trace_primary_lean<shadow>"),
                "contexts": n_ctx, "host_threads": n_ctx if threads else 1, "heavy_block_threshold": heavy, "frames": frames, "frame_ms_wall": frame_ms, "rays_last_frame": rays,

@@ -152,16 +152,40 @@ __global__ void k_tri_unpack(const TriangleData* __restrict__ tris, uint32_t nt,
     uv[0] = t.uv0[0], uv[1] = t.uv0[1], uv[2] = t.uv1[0], uv[3] = t.uv1[1], uv[4] = t.uv2[0], uv[5] = t.uv2[1];
 }
 
-template <bool WGSL>
-__global__ void k_aabb_pairs(const float* __restrict__ o, const float* __restrict__ d, uint32_t n_rays,
-                             const float* __restrict__ bmin, const float* __restrict__ bmax, uint32_t n_prims,
-                             float* __restrict__ out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)n_rays * n_prims) return;
-    uint32_t r = (uint32_t)(i / n_prims), p = (uint32_t)(i % n_prims);
-    V3 dd = ld3(d + 3 * (size_t)r);
-    V3 inv = v3(safe_inv<WGSL>(dd.x), safe_inv<WGSL>(dd.y), safe_inv<WGSL>(dd.z));
-    out[i] = slab(ld3(o + 3 * (size_t)r), inv, ld3(bmin + 3 * (size_t)p), ld3(bmax + 3 * (size_t)p));
+// Every (ray, box) pair. A thread keeps four consecutive boxes in registers and walks down the rays (blockIdx.y, then in
+// steps of gridDim.y): the ray and its safe inverse direction are the same for the whole workgroup and are formed once
+// per four pairs, the four results leave as one 16-byte store when every row of `out` starts on a 16-byte boundary
+// (WIDE: n_prims a multiple of four and `out` aligned). Per pair the arithmetic is safe_inv and slab, as before.
+template <bool WGSL, bool WIDE>
+__global__ __launch_bounds__(256) void k_aabb_pairs(const float* __restrict__ o, const float* __restrict__ d, uint32_t n_rays,
+                                                    const float* __restrict__ bmin, const float* __restrict__ bmax, uint32_t n_prims,
+                                                    float* __restrict__ out) {
+    const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (p0 >= n_prims) return;
+    const uint32_t np = n_prims - p0 < 4u ? n_prims - p0 : 4u;
+    V3 mn[4], mx[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t p = p0 + (k < np ? k : 0u);
+        mn[k] = ld3(bmin + 3 * (size_t)p);
+        mx[k] = ld3(bmax + 3 * (size_t)p);
+    }
+    for (uint32_t r = blockIdx.y; r < n_rays; r += gridDim.y) {
+        const V3 oo = ld3(o + 3 * (size_t)r), dd = ld3(d + 3 * (size_t)r);
+        const V3 inv = v3(safe_inv<WGSL>(dd.x), safe_inv<WGSL>(dd.y), safe_inv<WGSL>(dd.z));
+        float t[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) t[k] = slab(oo, inv, mn[k], mx[k]);
+        float* row = out + (size_t)r * n_prims + p0;
+        if (WIDE) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f4{t[0], t[1], t[2], t[3]}, reinterpret_cast<f4*>(row));  // written once, never read here
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (k < np) row[k] = t[k];
+        }
+    }
 }
 
 template <bool WGSL>
@@ -2082,17 +2106,24 @@ extern "C" int rt_intersect_aabb_pairs(rt_ctx* c, const float* origins, const fl
         RT_HIP(c, c->misc.reserve(2 * rb + 2 * pb + n * sizeof(float) + 64));
         char* base = c->misc.as<char>();
         d_o = (float*)base, d_d = (float*)(base + rb), d_mn = (float*)(base + 2 * rb), d_mx = (float*)(base + 2 * rb + pb);
-        d_out = (float*)(base + 2 * rb + 2 * pb);
+        d_out = (float*)(base + ((2 * rb + 2 * pb + 15) & ~(size_t)15));  // rows on 16-byte boundaries when n_prims allows
         RT_HIP(c, hipMemcpyAsync((void*)d_o, origins, rb, hipMemcpyHostToDevice, c->stream));
         RT_HIP(c, hipMemcpyAsync((void*)d_d, dirs, rb, hipMemcpyHostToDevice, c->stream));
         RT_HIP(c, hipMemcpyAsync((void*)d_mn, box_min, pb, hipMemcpyHostToDevice, c->stream));
         RT_HIP(c, hipMemcpyAsync((void*)d_mx, box_max, pb, hipMemcpyHostToDevice, c->stream));
     }
-    const dim3 grid((uint32_t)((n + 255) / 256));
+    // about 16 K workgroups in all: enough to fill the chip many times over, few enough that a thread's boxes serve many rays
+    const uint32_t gx = (n_prims + 1023u) / 1024u;
+    const uint32_t gy = std::min<uint32_t>(std::min<uint32_t>(n_rays, 65535u), std::max<uint32_t>(1u, 16384u / gx));
+    const dim3 grid(gx, gy);
+    const bool wide = (n_prims & 3u) == 0 && ((uintptr_t)d_out & 15u) == 0;
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_mn, d_mx, n_prims, d_out);
+    };
     if (c->params.wgsl_compat)
-        hipLaunchKernelGGL(k_aabb_pairs<true>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_mn, d_mx, n_prims, d_out);
+        wide ? launch(k_aabb_pairs<true, true>) : launch(k_aabb_pairs<true, false>);
     else
-        hipLaunchKernelGGL(k_aabb_pairs<false>, grid, dim3(256), 0, c->stream, d_o, d_d, n_rays, d_mn, d_mx, n_prims, d_out);
+        wide ? launch(k_aabb_pairs<false, true>) : launch(k_aabb_pairs<false, false>);
     RT_HIP(c, hipGetLastError());
     if (!dev) {
         RT_HIP(c, hipMemcpyAsync(out_t, d_out, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));

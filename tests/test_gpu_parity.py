@@ -93,6 +93,35 @@ def test_aabb_pairs_criterion_particle_scene(rt, ob, count, wgsl):
     core.close()
 
 
+@pytest.mark.parametrize("n_rays,n_prims", [(1, 1), (7, 3), (3, 1023), (300, 1025), (5, 4099), (20000, 64), (70001, 5), (33, 4096)])
+def test_aabb_pairs_ragged_sizes_host_and_device(rt, ob, n_rays, n_prims):
+    """Every (ray, box) pair for sizes that do not fill the kernel's units (four boxes a thread, 1024 a workgroup, rays
+    walked in steps of the grid's height), from host arrays and from device arrays, with the output on a 16-byte
+    boundary and off it: bit-equal to the CPU routine (src/math/ray.rs:3-36) each time, nothing written past the end."""
+    import torch
+    rng = np.random.default_rng(n_rays * 131 + n_prims)
+    o = rng.uniform(-30, 30, (n_rays, 3)).astype(np.float32)
+    d = rng.normal(size=(n_rays, 3)).astype(np.float32)
+    d[::5, 1] = 0.0  # safe-inverse branch
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    c = rng.uniform(-20, 20, (n_prims, 3)).astype(np.float32)
+    h = rng.uniform(0.1, 6, (n_prims, 3)).astype(np.float32)
+    mn, mx = c - h, c + h
+    want = ob.intersect_aabb_pairs(o, d, mn, mx, 0)
+    core = rt.TraceCore(0)
+    assert np.array_equal(bits(core.intersect_aabb_pairs(o, d, mn, mx)), bits(want))
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    do, dd, dmn, dmx = to(o), to(d), to(mn), to(mx)
+    for shift in (0, 1):  # output rows on 16-byte boundaries (when n_prims allows) and off them
+        buf = torch.full((n_rays * n_prims + 8,), -7.0, dtype=torch.float32, device="cuda")
+        out = buf[shift:shift + n_rays * n_prims].view(n_rays, n_prims)
+        core.intersect_aabb_pairs(do, dd, dmn, dmx, out=out)
+        core.sync()
+        assert np.array_equal(bits(out.cpu().numpy()), bits(want)), shift
+        assert bool((buf[:shift] == -7.0).all()) and bool((buf[shift + n_rays * n_prims:] == -7.0).all())
+    core.close()
+
+
 @pytest.mark.parametrize("wgsl", [0, 1])
 def test_tri_pairs(rt, ob, car_xyz9, wgsl):
     core = rt.TraceCore(0, rt.default_params(wgsl_compat=wgsl))

@@ -231,6 +231,41 @@ def animated(rt, dev, frames=int(os.environ.get("RT_ANIM_FRAMES", "200"))):
     return legs
 
 
+def bvh_benchmark(rt, dev, n_tris=1000000):
+    """The loop the reference's own example times (examples/massive_benchmark.rs:87-98,226-270): its scene, its tree
+    (BVHNode::build, src/core/bvh.rs:44-232 - built on the GPU, node for node the same), its ray set
+    (generate_test_rays) through its traversal (both children always), beside the grid walk on the same rays."""
+    from ray_tracer_amd import workloads as wl
+    core = rt.TraceCore(dev.index)
+    core.set_scene(None, wl.generate_test_triangles(n_tris))
+    core.build_bvh()  # the first build allocates
+    core.sync()
+    t0 = time.perf_counter()
+    st = core.build_bvh()
+    core.sync()
+    build_ms = (time.perf_counter() - t0) * 1e3
+    core.build_grid(cell_size=2.0)  # the tuned grid of this scene (mean occupancy 4-8)
+    legs = []
+    for n_rays in (100000, 2000000):  # the example's own count, and one that fills the GPU
+        o, d = wl.generate_test_rays(n_rays)
+        to, td = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        out = torch.empty(n_rays, dtype=torch.float32, device=dev)
+        hits = torch.empty((n_rays, 2), dtype=torch.int32, device=dev)
+        ms = _timed(core, lambda: core.trace_rays_bvh(to, td, out=out), 5)
+        gms = _timed(core, lambda: core.trace_rays(to, td, out=hits, n=n_rays), 5)
+        legs.append({"config": f"configs[2] massive_benchmark's own loop: {n_tris} triangles, BVH (the reference's tree, built on the GPU) "
+                               f"walked as the example walks it, generate_test_rays({n_rays})",
+                     "kernel": "kb_* (build), k_trace_bvh", "triangles": n_tris, "rays": n_rays, "bvh_nodes": st["node_count"],
+                     "bvh_depth": st["max_depth"], "bvh_build_ms_wall": build_ms, "ms": ms, "Mrays_per_s": n_rays / ms / 1e3,
+                     "hits": int((out >= 0).sum()), "grid_walk_same_rays_ms": gms, "grid_walk_Mrays_per_s": n_rays / gms / 1e3,
+                     "grid_walk_hits": int((hits[:, 0] != -1).sum()), "bound": "latency",
+                     "note": "the example opens both children of every node whose box the ray meets, no ordering, no pruning: the "
+                             "reference documents ~10-20 Mrays/s for it on its author's CPU (src/core/OPTIMIZATION_TOOLS.md:212); "
+                             "its box test loses hits on axis-aligned triangles that the grid walk finds (reproduced as is)"})
+    core.close()
+    return legs
+
+
 def all_legs(rt, dev):
     """Every leg, bounded to well under half a minute on one MI355X."""
     legs = []
@@ -239,6 +274,7 @@ def all_legs(rt, dev):
     legs += massive(rt, dev, 3840, 2160, (100000, 1000000), (1, 0))
     legs += animated(rt, dev)
     legs += massive(rt, dev, 7680, 4320, (1000000,), (1,), name="massive8k")
+    legs += bvh_benchmark(rt, dev)
     return legs, time.perf_counter() - t0
 
 
@@ -253,6 +289,8 @@ if __name__ == "__main__":
         print(json.dumps({"legs": legs, "wall_s": wall}))
     elif what == "criterion":
         print(json.dumps(criterion(rt, dev, reps or 50)))
+    elif what == "bvh":
+        print(json.dumps(bvh_benchmark(rt, dev)))
     elif what == "animated":
         print(json.dumps(animated(rt, dev)))
     elif what.startswith("massive"):  # e.g. massive4k_100000_skip, massive8k_1000000_skip: one leg, its launches repeated

@@ -207,6 +207,88 @@ __global__ __launch_bounds__(256) void k_trace_bvh(const float4* __restrict__ no
     out_t[i] = any ? best : -1.0f;
 }
 
+// The same walk with 32 lanes to a ray. The tree is cut into up to 32 subtrees (k_bvh_parts, once per build: the largest
+// subtree whose root is an inner node is replaced by its two children until there are 32); a lane first meets the boxes
+// of its subtree's ancestors - the example opens a node only if it met every box above it - and then walks its subtree
+// alone. The ray's answer is the smallest t any lane found: the minimum does not care who found what, so the result is
+// the one-lane walk's bit for bit, and a ray's dependent chain of node visits is a thirty-second as long.
+constexpr uint32_t BVH_PARTS = 32, BVH_PART_DEPTH = 31;
+struct BvhParts {
+    uint32_t n;
+    uint32_t first[BVH_PARTS], end[BVH_PARTS], n_above[BVH_PARTS];
+    uint32_t above[BVH_PARTS][BVH_PART_DEPTH];  // the ancestors of a part's root, from the tree's root down
+};
+
+__global__ void k_bvh_parts(const float4* __restrict__ nodes, uint32_t n_nodes, BvhParts* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    BvhParts& p = *out;
+    p.n = 1, p.first[0] = 0, p.end[0] = n_nodes, p.n_above[0] = 0;
+    while (p.n < BVH_PARTS) {
+        uint32_t pick = BVH_PARTS, size = 0;
+        for (uint32_t k = 0; k < p.n; ++k) {
+            const bool inner = __float_as_uint(nodes[2 * (size_t)p.first[k] + 1].w) == 0u;
+            if (inner && p.n_above[k] < BVH_PART_DEPTH && p.end[k] - p.first[k] > size) pick = k, size = p.end[k] - p.first[k];
+        }
+        if (pick == BVH_PARTS) break;
+        const uint32_t root = p.first[pick], left = root + 1, right = __float_as_uint(nodes[2 * (size_t)left].w), m = p.n++;
+        for (uint32_t a = 0; a < p.n_above[pick]; ++a) p.above[m][a] = p.above[pick][a];
+        p.above[pick][p.n_above[pick]] = p.above[m][p.n_above[pick]] = root;
+        p.n_above[m] = ++p.n_above[pick];
+        p.first[m] = right, p.end[m] = p.end[pick];
+        p.first[pick] = left, p.end[pick] = right;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_trace_bvh_parts(const float4* __restrict__ nodes, const uint32_t* __restrict__ leaf_first,
+                                                         const BvhParts* __restrict__ parts, const float4* __restrict__ recs,
+                                                         const float* __restrict__ origins, const float* __restrict__ dirs,
+                                                         uint32_t n, float* __restrict__ out_t) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = (uint32_t)(t / BVH_PARTS), part = (uint32_t)(t % BVH_PARTS);
+    float best = INFINITY;
+    if (i < n && part < parts->n) {
+        const V3 o = ld3(origins + 3 * (size_t)i), d = ld3(dirs + 3 * (size_t)i);
+        const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        auto meets = [&](const float4& a, const float4& b) {
+            const V3 t1 = (v3(a.x, a.y, a.z) - o) * inv, t2 = (v3(b.x, b.y, b.z) - o) * inv;
+            const V3 lo = vmin(t1, t2), hi = vmax(t1, t2);
+            const float tmin = fmaxf(fmaxf(lo.x, lo.y), lo.z), tmax = fminf(fminf(hi.x, hi.y), hi.z);
+            return tmax >= tmin && tmax >= 0.0f;
+        };
+        bool open = true;
+        for (uint32_t a = 0; a < parts->n_above[part] && open; ++a) {
+            const uint32_t up = parts->above[part][a];
+            open = meets(nodes[2 * (size_t)up], nodes[2 * (size_t)up + 1]);
+        }
+        if (open) {
+            const RayPk rp = make_ray_pk(o, d);
+            uint32_t node = parts->first[part];
+            const uint32_t end = parts->end[part];
+            while (node < end) {
+                const float4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
+                const uint32_t skip = __float_as_uint(a.w), count = __float_as_uint(b.w);
+                if (!meets(a, b)) {
+                    node = skip;
+                    continue;
+                }
+                if (count) {
+                    const uint32_t first = leaf_first[node];
+                    for (uint32_t k = 0; k < count; ++k) {
+                        const size_t r = 3 * (size_t)(first + k);
+                        const float tt = moller_trumbore_pk<false>(rp, recs[r], recs[r + 1], recs[r + 2]);
+                        if (tt >= 0.0f && tt < best) best = tt;
+                    }
+                    node = skip;
+                } else {
+                    node = node + 1;
+                }
+            }
+        }
+    }
+    for (int step = BVH_PARTS / 2; step > 0; step >>= 1) best = fminf(best, __shfl_xor(best, step, BVH_PARTS));
+    if (i < n && part == 0) out_t[i] = best < INFINITY ? best : -1.0f;
+}
+
 
 // ---- the same tree, built on the GPU ----------------------------------------------------------------------------
 // Level by level: every node of a level is a segment [lo, hi) of the index array. Per level, one pass each over the
@@ -227,6 +309,15 @@ __global__ __launch_bounds__(256) void k_trace_bvh(const float4* __restrict__ no
 //     big started).
 // Checked against the loop itself for every 0/1 array of up to 11 elements and 20 000 random ones
 // (tests/test_bvh_partition_rule.py), and node for node against the host recursion on the GPU.
+// the finished tree (bvh_nodes, bvh_n_nodes) cut into parts for k_trace_bvh_parts; waits for the stream
+static int cut_into_parts(rt_ctx* c) {
+    RT_HIP(c, c->bvh_parts.reserve(sizeof(BvhParts)));
+    hipLaunchKernelGGL(k_bvh_parts, dim3(1), dim3(64), 0, c->stream, c->bvh_nodes.as<float4>(), c->bvh_n_nodes, c->bvh_parts.as<BvhParts>());
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr uint32_t BIN_WORDS = 3 * SAH_BUCKETS * 7;  // per axis and bucket: count, min.xyz, max.xyz (keys)
 
@@ -693,6 +784,7 @@ extern "C" int rt_build_bvh(rt_ctx* c) {
         return fail_free(fail(c, RT_ERR_HIP, "rt_build_bvh: a kernel failed"));
     c->bvh_stats = rt_bvh_stats{made, h[2], h[3], n};
     c->bvh_n_nodes = made;
+    if (int r = cut_into_parts(c)) return fail_free(r);
     c->has_bvh = true;
     return RT_OK;
 }
@@ -746,6 +838,7 @@ extern "C" int rt_build_bvh_host(rt_ctx* c) {
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->bvh_stats = b.stats;
     c->bvh_n_nodes = (uint32_t)nn;
+    if (int r = cut_into_parts(c)) return r;
     c->has_bvh = true;
     return RT_OK;
 }
@@ -780,8 +873,18 @@ extern "C" int rt_trace_rays_bvh(rt_ctx* c, const float* origins, const float* d
         RT_HIP(c, hipMemcpyAsync(c->in_d.p, dirs, rb, hipMemcpyHostToDevice, c->stream));
         d_o = c->in_o.as<float>(), d_d = c->in_d.as<float>(), d_out = c->out_p.as<float>();
     }
-    hipLaunchKernelGGL(k_trace_bvh, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->bvh_nodes.as<float4>(),
-                       c->bvh_leaf_first.as<uint32_t>(), c->bvh_n_nodes, c->bvh_recs.as<float4>(), d_o, d_d, n, d_out);
+    // 32 lanes to a ray while that does not oversubscribe the chip (1 563 waves of 100 000 one-lane rays leave it idle behind
+    // their dependent chains: 3.5 -> 1.5 ms; 2 M rays fill it one lane each, and the parts' repeated ancestor tests and
+    // uneven sizes cost them 4.3 -> 16 ms). RT_BVH_LANES=1 / 32 (development, tests): that walk whatever the count.
+    const char* lanes = getenv("RT_BVH_LANES");
+    const bool one_lane = lanes ? atoi(lanes) == 1 : n > 262144u;
+    if (one_lane)
+        hipLaunchKernelGGL(k_trace_bvh, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->bvh_nodes.as<float4>(),
+                           c->bvh_leaf_first.as<uint32_t>(), c->bvh_n_nodes, c->bvh_recs.as<float4>(), d_o, d_d, n, d_out);
+    else
+        hipLaunchKernelGGL(k_trace_bvh_parts, dim3((uint32_t)(((size_t)n * BVH_PARTS + 255) / 256)), dim3(256), 0, c->stream,
+                           c->bvh_nodes.as<float4>(), c->bvh_leaf_first.as<uint32_t>(), c->bvh_parts.as<BvhParts>(),
+                           c->bvh_recs.as<float4>(), d_o, d_d, n, d_out);
     RT_HIP(c, hipGetLastError());
     if (!dev) {
         RT_HIP(c, hipMemcpyAsync(out_t, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));

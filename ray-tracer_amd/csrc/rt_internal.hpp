@@ -127,7 +127,7 @@ struct rt_ctx {
     uint32_t skin_nv = 0, skin_max_joint = 0;
     bool has_skin = false;
     // bounding volume hierarchy (rt_build_bvh)
-    rt::DevBuf bvh_nodes, bvh_leaf_first, bvh_prims, bvh_recs, bvh_work;
+    rt::DevBuf bvh_nodes, bvh_leaf_first, bvh_prims, bvh_recs, bvh_work, bvh_parts;
     rt_bvh_stats bvh_stats{};
     uint32_t bvh_n_nodes = 0;
     bool has_bvh = false;

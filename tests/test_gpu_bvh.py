@@ -13,9 +13,18 @@ def check(core, ob, tris, o, d, what):
     assert (st["node_count"], st["leaf_count"], st["max_depth"], st["total_primitives"]) == \
         (want_st["nodes"], want_st["leaves"], want_st["max_depth"], want_st["prims"]), what
     want, hits = b.trace(o, d, n_threads=4)
-    got = core.trace_rays_bvh(o, d)
-    bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
-    assert bad.size == 0, f"{what}: {bad.size} of {len(o)} t values differ, first {bad[:5]}: {got[bad[:5]]} vs {want[bad[:5]]}"
+    import os
+    for lanes in ("1", "32", None):  # a lane to a ray, 32 lanes to a ray over the tree's parts, the library's own choice
+        if lanes is None:
+            os.environ.pop("RT_BVH_LANES", None)
+        else:
+            os.environ["RT_BVH_LANES"] = lanes
+        try:
+            got = core.trace_rays_bvh(o, d)
+        finally:
+            os.environ.pop("RT_BVH_LANES", None)
+        bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+        assert bad.size == 0, f"{what}, lanes {lanes}: {bad.size} of {len(o)} t values differ, first {bad[:5]}: {got[bad[:5]]} vs {want[bad[:5]]}"
     return want, hits
 
 
@@ -29,7 +38,13 @@ def test_reference_known_answers(core, ob, rt):
     core.set_scene(None, one)
     core.build_bvh()
     t = core.trace_rays_bvh(np.array([[0, 0, 0], [0, 0, 0]], np.float32), np.array([[0, 0, -1], [0, 1, 0]], np.float32))
-    assert t[0] == np.float32(5.0) and t[1] == np.float32(-1.0)
+    assert t[0] == np.float32(5.0) and t[1] == np.float32(-1.0)  # a tree of one leaf: one part
+    # trees of 2 .. 40 triangles: fewer parts than lanes, parts that are single leaves
+    for n in (2, 5, 6, 9, 17, 40):
+        tris = ob.generate_test_triangles(n)
+        core.set_scene(None, tris)
+        o, d = ob.generate_test_rays(300)
+        check(core, ob, tris, o, d, f"{n} triangles")
 
 
 def test_generator_scenes(core, ob, rt):

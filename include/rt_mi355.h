@@ -380,7 +380,10 @@ int rt_get_bvh_stats(rt_ctx* ctx, rt_bvh_stats* stats);
 int rt_read_bvh(rt_ctx* ctx, float* nodes, uint32_t* leaf_first, uint32_t* prims);
 /* traverse_bvh_triangles of the reference's benchmark (examples/massive_benchmark.rs:226-270,311-320) for a list
  * of rays: both children of every node whose box the ray meets, Moller-Trumbore in the leaves, smallest t.
- * out_t[i] = t, or -1 when nothing is hit (the example's None). origins/dirs/out_t all host or all device. */
+ * out_t[i] = t, or -1 when nothing is hit (the example's None). origins/dirs/out_t all host or all device.
+ * Two things are done differently without changing a bit of out_t: a triangle that is an exact copy of the one before
+ * it in its leaf is not tested again (rt_params.skip_duplicate_triangles; the same t cannot lower the minimum), and up
+ * to 262 144 rays are walked by 32 lanes each, a lane per subtree (the minimum over the lanes is the ray's). */
 int rt_trace_rays_bvh(rt_ctx* ctx, const float* origins, const float* dirs, uint32_t n, float* out_t);
 
 /* ---- skinning (animated models) --------------------------------------------------------- */

@@ -154,13 +154,24 @@ struct Builder {
     }
 };
 
+// mark_copies: the spare word of record k says whether triangle k of the leaf order is, bit for bit, the triangle before
+// it. A copy gives the same t as its original, and the walk keeps the smallest t only, so a leaf's loop passes over
+// records marked so that follow another record of the SAME leaf (the loop never skips a leaf's first record). The
+// reference's generator makes such scenes (src/core/benchmark.rs:102-105: 10 000 positions, repeated), and its builder
+// cannot separate copies - they share a centroid -, so they end up side by side in one leaf.
 __global__ void k_bvh_records(const uint32_t* __restrict__ prims, uint32_t n, const float* __restrict__ tri_v,
-                              float4* __restrict__ recs) {
+                              float4* __restrict__ recs, int mark_copies) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const float* v = tri_v + 9 * (size_t)prims[k];
     const V3 v0 = ld3(v), e1 = ld3(v + 3) - v0, e2 = ld3(v + 6) - v0;
-    recs[3 * (size_t)k] = make_float4(v0.x, v0.y, v0.z, 0.f);
+    bool copy = mark_copies != 0 && k > 0;
+    if (copy) {
+        const uint32_t* a = reinterpret_cast<const uint32_t*>(v);
+        const uint32_t* b = reinterpret_cast<const uint32_t*>(tri_v + 9 * (size_t)prims[k - 1]);
+        for (int w = 0; w < 9; ++w) copy = copy && a[w] == b[w];
+    }
+    recs[3 * (size_t)k] = make_float4(v0.x, v0.y, v0.z, __uint_as_float(copy ? 1u : 0u));
     recs[3 * (size_t)k + 1] = make_float4(e1.x, e1.y, e1.z, 0.f);
     recs[3 * (size_t)k + 2] = make_float4(e2.x, e2.y, e2.z, 0.f);
 }
@@ -193,7 +204,9 @@ __global__ __launch_bounds__(256) void k_trace_bvh(const float4* __restrict__ no
             const uint32_t first = leaf_first[node];
             for (uint32_t k = 0; k < count; ++k) {
                 const size_t r = 3 * (size_t)(first + k);
-                const float t = moller_trumbore_pk<false>(rp, recs[r], recs[r + 1], recs[r + 2]);
+                const float4 c0 = recs[r];
+                if (k != 0 && __float_as_uint(c0.w) != 0u) continue;  // a copy of the record before it: the same t
+                const float t = moller_trumbore_pk<false>(rp, c0, recs[r + 1], recs[r + 2]);
                 if (t >= 0.0f && t < best) {  // the routine returns Some(t) only for t >= 1e-6
                     best = t;
                     any = true;
@@ -275,7 +288,9 @@ __global__ __launch_bounds__(256) void k_trace_bvh_parts(const float4* __restric
                     const uint32_t first = leaf_first[node];
                     for (uint32_t k = 0; k < count; ++k) {
                         const size_t r = 3 * (size_t)(first + k);
-                        const float tt = moller_trumbore_pk<false>(rp, recs[r], recs[r + 1], recs[r + 2]);
+                        const float4 c0 = recs[r];
+                        if (k != 0 && __float_as_uint(c0.w) != 0u) continue;  // a copy of the record before it: the same t
+                        const float tt = moller_trumbore_pk<false>(rp, c0, recs[r + 1], recs[r + 2]);
                         if (tt >= 0.0f && tt < best) best = tt;
                     }
                     node = skip;
@@ -778,7 +793,8 @@ extern "C" int rt_build_bvh(rt_ctx* c) {
     uint32_t h[4] = {0, 0, 0, 0};
     if (hipMemcpyAsync(c->bvh_prims.p, idx_a, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail_free(fail(c, RT_ERR_HIP, "rt_build_bvh: copy"));
-    hipLaunchKernelGGL(k_bvh_records, per_prim, tb, 0, st, c->bvh_prims.as<uint32_t>(), n, c->tri_v.as<float>(), c->bvh_recs.as<float4>());
+    hipLaunchKernelGGL(k_bvh_records, per_prim, tb, 0, st, c->bvh_prims.as<uint32_t>(), n, c->tri_v.as<float>(), c->bvh_recs.as<float4>(),
+                       (int)c->params.skip_duplicate_triangles);
     if (hipMemcpyAsync(h, counters, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
         hipGetLastError() != hipSuccess)
         return fail_free(fail(c, RT_ERR_HIP, "rt_build_bvh: a kernel failed"));
@@ -833,7 +849,7 @@ extern "C" int rt_build_bvh_host(rt_ctx* c) {
     RT_HIP(c, hipMemcpyAsync(c->bvh_leaf_first.p, b.leaf_first.data(), nn * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     RT_HIP(c, hipMemcpyAsync(c->bvh_prims.p, b.prims.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_bvh_records, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, c->stream, c->bvh_prims.as<uint32_t>(),
-                       (uint32_t)np, c->tri_v.as<float>(), c->bvh_recs.as<float4>());
+                       (uint32_t)np, c->tri_v.as<float>(), c->bvh_recs.as<float4>(), (int)c->params.skip_duplicate_triangles);
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->bvh_stats = b.stats;

@@ -87,6 +87,29 @@ def test_car_frame_rays_and_degenerate_directions(core, ob, rt, car_xyz9):
         core.trace_rays_bvh(o, d)
 
 
+def test_copies_in_a_leaf_are_passed_over_exactly(ob, rt):
+    """The generator's scenes hold every triangle many times over; copies share a leaf, and the walk tests the first of a
+    run only (rt_params.skip_duplicate_triangles, on by default). Same t bits with the switch off, and as the oracle
+    - which tests everything - has them; also for a scene where copies are NOT neighbours in their leaf (two different
+    triangles with one centroid, interleaved), which must lose nothing."""
+    o, d = ob.generate_test_rays(4000)
+    tris = ob.generate_test_triangles(50000)  # five copies of each
+    a = np.array([[-1, -1, -5, 1, -1, -5, 0, 2, -5]], np.float32)
+    b = np.array([[-1, 1, -6, 1, 1, -6, 0, -2, -6]], np.float32)  # same centroid as a
+    mixed = ob.triangles_from_xyz9(np.concatenate([a, b, a, b, b, a, a, a, b], axis=0))
+    o2 = np.array([[0, 0, 0], [0.3, 0.2, 0], [0, 0, -5.5], [5, 5, 0]], np.float32)
+    d2 = np.array([[0, 0, -1], [0, 0, -1], [0, 0, -1], [0, 0, -1]], np.float32)
+    for scene, oo, dd in ((tris, o, d), (mixed, o2, d2)):
+        got = []
+        for skip in (1, 0):
+            core = rt.TraceCore(0, rt.default_params(skip_duplicate_triangles=skip))
+            core.set_scene(None, scene)
+            want, hits = check(core, ob, scene, oo, dd, f"skip {skip}")
+            got.append(want)
+            core.close()
+        assert hits > 0 and np.array_equal(got[0].view(np.uint32), got[1].view(np.uint32))
+
+
 def same_tree(core, what):
     """rt_build_bvh (GPU, level by level) against rt_build_bvh_host (the reference's recursion): node for node."""
     st_gpu = core.build_bvh()

@@ -104,29 +104,37 @@ __global__ void k_box_frame(const BoxData* __restrict__ boxes, uint32_t nb, floa
     out[4 * (size_t)i + 3] = make_float4(half.x, half.y, half.z, 0.f);
 }
 
-// Linear-blend skinning, one lane per triangle corner: S = ((w0*M[j0] + w1*M[j1]) + w2*M[j2]) + w3*M[j3] element
+// Linear-blend skinning of a triangle's corners: S = ((w0*M[j0] + w1*M[j1]) + w2*M[j2]) + w3*M[j3] element
 // by element, then the point transform ((S.x*p.x + S.y*p.y) + S.z*p.z) + S.w (columns of S; glam's
 // transform_point3 order). Matrices are column-major, one per joint. Writes the trace's vertex array directly,
 // so the binning pass that follows reads what this kernel wrote without a trip through the host.
-__global__ void k_skin(const float* __restrict__ pos, const ushort4* __restrict__ joints, const float4* __restrict__ weights,
-                       const uint32_t* __restrict__ tri_idx, uint32_t n_corners, const float4* __restrict__ mats,
-                       float* __restrict__ tri_v) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_corners) return;
-    const uint32_t v = tri_idx[k];
-    const V3 p = ld3(pos + 3 * (size_t)v);
-    const ushort4 j = joints[v];
-    const float4 w = weights[v];
-    V3 col[4];
+// One thread = one triangle: its three corners, then its geometric normal (normalize(cross(v1 - v0, v2 - v0)),
+// src/core/triangle_intersection.rs:79) - one launch per frame instead of one per corner array and one per normal array: a
+// frame of an animated model is a chain of small launches, and each costs about as much as this one's work.
+__global__ void k_skin_triangles(const float* __restrict__ pos, const ushort4* __restrict__ joints, const float4* __restrict__ weights,
+                                 const uint32_t* __restrict__ tri_idx, uint32_t nt, const float4* __restrict__ mats,
+                                 float* __restrict__ tri_v, float4* __restrict__ tri_n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    V3 corner[3];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float4 a = mats[4 * j.x + c], b = mats[4 * j.y + c], d = mats[4 * j.z + c], e = mats[4 * j.w + c];
-        col[c] = ((v3(a.x, a.y, a.z) * w.x + v3(b.x, b.y, b.z) * w.y) + v3(d.x, d.y, d.z) * w.z) + v3(e.x, e.y, e.z) * w.w;
+    for (uint32_t k = 0; k < 3; ++k) {
+        const uint32_t v = tri_idx[3 * (size_t)t + k];
+        const V3 p = ld3(pos + 3 * (size_t)v);
+        const ushort4 j = joints[v];
+        const float4 w = weights[v];
+        V3 col[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 a = mats[4 * j.x + c], b = mats[4 * j.y + c], d = mats[4 * j.z + c], e = mats[4 * j.w + c];
+            col[c] = ((v3(a.x, a.y, a.z) * w.x + v3(b.x, b.y, b.z) * w.y) + v3(d.x, d.y, d.z) * w.z) + v3(e.x, e.y, e.z) * w.w;
+        }
+        corner[k] = ((col[0] * p.x + col[1] * p.y) + col[2] * p.z) + col[3];
+        float* o = tri_v + 9 * (size_t)t + 3 * k;
+        o[0] = corner[k].x, o[1] = corner[k].y, o[2] = corner[k].z;
     }
-    const V3 out = ((col[0] * p.x + col[1] * p.y) + col[2] * p.z) + col[3];
-    tri_v[3 * (size_t)k] = out.x;
-    tri_v[3 * (size_t)k + 1] = out.y;
-    tri_v[3 * (size_t)k + 2] = out.z;
+    const V3 n = normalize(cross(corner[1] - corner[0], corner[2] - corner[0]));
+    tri_n[t] = make_float4(n.x, n.y, n.z, 0.f);
 }
 
 // Geometric normal per triangle: normalize(cross(v1 - v0, v2 - v0)) (src/core/triangle_intersection.rs:79).
@@ -1858,12 +1866,9 @@ extern "C" int rt_skin_vertices(rt_ctx* c, const float* joint_matrices, uint32_t
         RT_HIP(c, hipMemcpyAsync(c->skin_mats.p, joint_matrices, (size_t)n_joints * 64, hipMemcpyHostToDevice, c->stream));
         mats = c->skin_mats.as<float4>();
     }
-    const uint32_t corners = c->nt * 3;
-    hipLaunchKernelGGL(k_skin, dim3((corners + 255) / 256), dim3(256), 0, c->stream, c->skin_pos.as<float>(),
-                       c->skin_joints.as<ushort4>(), c->skin_weights.as<float4>(), c->skin_tri.as<uint32_t>(), corners, mats,
-                       c->tri_v.as<float>());
-    hipLaunchKernelGGL(k_tri_normals, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->tri_v.as<float>(), 0u, c->nt,
-                       c->tri_n.as<float4>());
+    hipLaunchKernelGGL(k_skin_triangles, dim3((c->nt + 255) / 256), dim3(256), 0, c->stream, c->skin_pos.as<float>(),
+                       c->skin_joints.as<ushort4>(), c->skin_weights.as<float4>(), c->skin_tri.as<uint32_t>(), c->nt, mats,
+                       c->tri_v.as<float>(), c->tri_n.as<float4>());
     RT_HIP(c, hipGetLastError());
     if (!dev) RT_HIP(c, hipStreamSynchronize(c->stream));  // the caller may reuse its matrix array
     c->has_grid = false;  // cell lists and reference records are stale now

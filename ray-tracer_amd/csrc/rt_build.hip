@@ -406,19 +406,26 @@ __device__ inline BinGrid fast_grid(const FastMeta& m, float cell, uint32_t nb, 
     return g;
 }
 
-// One workgroup: bounds of all objects, padded; dimensions; capacity checks.
-__global__ __launch_bounds__(1024) void kf_bounds_dims(const BoxData* __restrict__ boxes, const float* __restrict__ tri_v, uint32_t nb,
-                                                      uint32_t total, float cell_size, int tri_mode, FastCaps caps,
-                                                      FastMeta* __restrict__ meta) {
+// Bounds, dimensions, per-object pair counts and their scan in ONE workgroup and one launch (the rebuild of a small
+// scene is a chain of launches that each cost as much as their work): the bounds of all objects, padded, the grid's
+// dimensions and the capacity checks; the per-cell counters cleared; then every thread takes a run of consecutive objects, counts their cells,
+// the workgroup scans the threads' totals, and every thread writes the exclusive prefix of its run (obj_off[total] = all
+// pairs, as the scan of a closing zero gave). Sums wrap in 32 bits as the library scan's did; the 64-bit total goes to
+// meta->n_pairs, which is what the capacity checks read.
+__global__ __launch_bounds__(1024) void kf_head(const BoxData* __restrict__ boxes, const float* __restrict__ tri_v, uint32_t nb, uint32_t nt,
+                                               float cell_size, int tri_mode, FastCaps caps, FastMeta* __restrict__ meta,
+                                               uint32_t* __restrict__ obj_off, uint32_t* __restrict__ counts, uint32_t n_counts) {
     __shared__ float red[6][1024];
+    __shared__ FastMeta sm;
+    __shared__ unsigned long long part[1024];
+    const uint32_t t = threadIdx.x, total = nb + nt;
     V3 mn = v3(INFINITY, INFINITY, INFINITY), mx = v3(-INFINITY, -INFINITY, -INFINITY);
-    for (uint32_t id = threadIdx.x; id < total; id += 1024) {
+    for (uint32_t id = t; id < total; id += 1024) {
         V3 a, b;
         object_bounds(boxes, tri_v, nb, id, a, b);
         mn = vmin(mn, a);
         mx = vmax(mx, b);
     }
-    const uint32_t t = threadIdx.x;
     red[0][t] = mn.x, red[1][t] = mn.y, red[2][t] = mn.z;
     red[3][t] = mx.x, red[4][t] = mx.y, red[5][t] = mx.z;
     __syncthreads();
@@ -429,60 +436,70 @@ __global__ __launch_bounds__(1024) void kf_bounds_dims(const BoxData* __restrict
         }
         __syncthreads();
     }
-    if (t != 0) return;
-    FastMeta m;
-    memset(&m, 0, sizeof(m));
-    const V3 bmin = v3(red[0][0], red[1][0], red[2][0]) - v3(1.0f, 1.0f, 1.0f);  // src/grid.rs:130-134
-    const V3 bmax = v3(red[3][0], red[4][0], red[5][0]) + v3(1.0f, 1.0f, 1.0f);
-    m.bmin[0] = bmin.x, m.bmin[1] = bmin.y, m.bmin[2] = bmin.z;
-    m.bmax[0] = bmax.x, m.bmax[1] = bmax.y, m.bmax[2] = bmax.z;
-    const V3 e = bmax - bmin;
-    const float ext[3] = {e.x, e.y, e.z};
-    const float div = tri_mode ? fmaxf(cell_size, RT_TRI_MIN_CELL_SIZE) : cell_size;
-    unsigned long long dims[3];
-    for (int k = 0; k < 3; ++k) {  // src/grid.rs:9-16; src/grid_triangles.rs:126-139
-        const float q = ceilf(ext[k] / div);
-        unsigned long long v = !(q > 0.0f) ? 0ull : (q >= 4294967296.0f ? 0xFFFFFFFFull : (unsigned long long)q);
-        if (tri_mode) v = v < 1 ? 1 : (v > RT_TRI_MAX_GRID_DIM ? RT_TRI_MAX_GRID_DIM : v);
-        dims[k] = v;
+    if (t == 0) {
+        FastMeta m;
+        memset(&m, 0, sizeof(m));
+        const V3 bmin = v3(red[0][0], red[1][0], red[2][0]) - v3(1.0f, 1.0f, 1.0f);  // src/grid.rs:130-134
+        const V3 bmax = v3(red[3][0], red[4][0], red[5][0]) + v3(1.0f, 1.0f, 1.0f);
+        m.bmin[0] = bmin.x, m.bmin[1] = bmin.y, m.bmin[2] = bmin.z;
+        m.bmax[0] = bmax.x, m.bmax[1] = bmax.y, m.bmax[2] = bmax.z;
+        const V3 e = bmax - bmin;
+        const float ext[3] = {e.x, e.y, e.z};
+        const float div = tri_mode ? fmaxf(cell_size, RT_TRI_MIN_CELL_SIZE) : cell_size;
+        unsigned long long dims[3];
+        for (int k = 0; k < 3; ++k) {  // src/grid.rs:9-16; src/grid_triangles.rs:126-139
+            const float q = ceilf(ext[k] / div);
+            unsigned long long v = !(q > 0.0f) ? 0ull : (q >= 4294967296.0f ? 0xFFFFFFFFull : (unsigned long long)q);
+            if (tri_mode) v = v < 1 ? 1 : (v > RT_TRI_MAX_GRID_DIM ? RT_TRI_MAX_GRID_DIM : v);
+            dims[k] = v;
+        }
+        const bool bad = dims[0] == 0 || dims[1] == 0 || dims[2] == 0 || dims[0] > 0xFFFFull * 16 || dims[1] > 0xFFFFull * 16 ||
+                         dims[2] > 0xFFFFull * 16;
+        unsigned long long cells = bad ? 0 : dims[0] * dims[1] * dims[2];
+        const unsigned long long bordered = bad ? 0 : (dims[0] + 2) * (dims[1] + 2) * (dims[2] + 2);
+        if (bad || cells > caps.cells || bordered > caps.bordered) {
+            m.overflow = 1;
+            cells = 0;
+        }
+        m.gx = (uint32_t)dims[0], m.gy = (uint32_t)dims[1], m.gz = (uint32_t)dims[2];
+        m.n_cells = (uint32_t)cells;
+        sm = m;
+        *meta = m;
     }
-    const bool bad = dims[0] == 0 || dims[1] == 0 || dims[2] == 0 || dims[0] > 0xFFFFull * 16 || dims[1] > 0xFFFFull * 16 ||
-                     dims[2] > 0xFFFFull * 16;
-    unsigned long long cells = bad ? 0 : dims[0] * dims[1] * dims[2];
-    unsigned long long bordered = bad ? 0 : (dims[0] + 2) * (dims[1] + 2) * (dims[2] + 2);
-    if (bad || cells > caps.cells || bordered > caps.bordered) {
-        m.overflow = 1;
-        cells = 0;
-    }
-    m.gx = (uint32_t)dims[0], m.gy = (uint32_t)dims[1], m.gz = (uint32_t)dims[2];
-    m.n_cells = (uint32_t)cells;
-    *meta = m;
-}
-
-__global__ __launch_bounds__(256) void kf_obj_pairs(FastMeta* __restrict__ meta, float cell, uint32_t nb, uint32_t nt, int tri_mode,
-                                                    const BoxData* __restrict__ boxes, const float* __restrict__ tri_v,
-                                                    uint32_t* __restrict__ obj_n, uint32_t* __restrict__ counts, uint32_t n_counts) {
-    __shared__ unsigned long long wg_sum;
-    if (threadIdx.x == 0) wg_sum = 0;
     __syncthreads();
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    // the per-cell counters start at zero (the counting kernel runs two launches later)
-    for (uint32_t k = id; k < n_counts; k += gridDim.x * blockDim.x) counts[k] = 0;
-    const uint32_t total = nb + nt;
-    uint32_t n = 0;
-    if (id < total && !meta->overflow) {
-        const BinGrid g = fast_grid(*meta, cell, nb, nt, tri_mode);
-        V3 mn, mx;
-        object_bounds(boxes, tri_v, nb, id, mn, mx);
-        const Range3 r = cell_range(g, mn, mx);
-        const unsigned long long v = (unsigned long long)(r.hi[0] - r.lo[0] + 1) * (unsigned long long)(r.hi[1] - r.lo[1] + 1) *
-                                     (unsigned long long)(r.hi[2] - r.lo[2] + 1);
-        n = r.lo[0] > r.hi[0] ? 0u : (v > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)v);
+    for (uint32_t k = t; k < n_counts; k += 1024) counts[k] = 0;  // the per-cell counters start at zero
+    const uint32_t per = (total + 1 + 1023) / 1024;
+    const uint32_t a = t * per < total + 1 ? t * per : total + 1, b = a + per < total + 1 ? a + per : total + 1;
+    const BinGrid g = fast_grid(sm, cell_size, nb, nt, tri_mode);
+    unsigned long long sum = 0;
+    for (uint32_t id = a; id < b; ++id) {
+        uint32_t n = 0;
+        if (id < total && !sm.overflow) {
+            V3 lo, hi;
+            object_bounds(boxes, tri_v, nb, id, lo, hi);
+            const Range3 r = cell_range(g, lo, hi);
+            const unsigned long long v = (unsigned long long)(r.hi[0] - r.lo[0] + 1) * (unsigned long long)(r.hi[1] - r.lo[1] + 1) *
+                                         (unsigned long long)(r.hi[2] - r.lo[2] + 1);
+            n = r.lo[0] > r.hi[0] ? 0u : (v > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)v);
+        }
+        obj_off[id] = n;
+        sum += n;
     }
-    if (id <= total) obj_n[id] = n;  // entry `total` closes the scan
-    if (n) atomicAdd(&wg_sum, (unsigned long long)n);
+    part[t] = sum;
     __syncthreads();
-    if (threadIdx.x == 0 && wg_sum) atomicAdd(&meta->n_pairs, wg_sum);
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive scan of the threads' totals
+        const unsigned long long below = t >= off ? part[t - off] : 0ull;
+        __syncthreads();
+        part[t] += below;
+        __syncthreads();
+    }
+    unsigned long long run = part[t] - sum;
+    for (uint32_t id = a; id < b; ++id) {
+        const uint32_t n = obj_off[id];
+        obj_off[id] = (uint32_t)run;
+        run += n;
+    }
+    if (t == 1023) meta->n_pairs = part[1023];
 }
 
 // One lane per (object, cell) pair: the pair's cell, id and its slot in the cell's list (arbitrary order).
@@ -755,7 +772,7 @@ static int build_grid_fast(rt_ctx* c, float cell_size, uint32_t max_per_cell, in
     const BoxData* boxes = c->boxes.as<BoxData>();
     const float* tri_v = c->tri_v.as<float>();
     uint32_t *counts = c->b_counts.as<uint32_t>(), *tmp_start = c->b_tmp_start.as<uint32_t>();
-    uint32_t *final_start = c->cell_start.as<uint32_t>(), *obj_n = c->b_obj_n.as<uint32_t>(), *obj_off = c->b_obj_off.as<uint32_t>();
+    uint32_t *final_start = c->cell_start.as<uint32_t>(), *obj_off = c->b_obj_off.as<uint32_t>();
     uint32_t *slots = c->b_flags.as<uint32_t>(), *tmp_ids = c->b_tmp_ids.as<uint32_t>(), *pair_id = c->b_tmp_sorted.as<uint32_t>();
     uint32_t* pair_cell = c->b_tmp_cell.as<uint32_t>();
     // launches cover what the last build needed plus a margin, never more than the buffers hold: a frame that needs
@@ -766,15 +783,10 @@ static int build_grid_fast(rt_ctx* c, float cell_size, uint32_t max_per_cell, in
     lim.bordered = (uint32_t)reach(c->fast_bordered, caps.bordered);
     lim.pairs = (uint32_t)reach(c->fast_pairs, caps.pairs);
     lim.refs = (uint32_t)reach(c->n_refs, caps.refs);
-    hipLaunchKernelGGL(kf_bounds_dims, dim3(1), dim3(1024), 0, st, boxes, tri_v, nb, total, cell_size, tm, lim, meta);
-    hipLaunchKernelGGL(kf_obj_pairs, dim3((total + 1 + 255) / 256), dim3(256), 0, st, meta, cell_size, nb, nt, tm, boxes, tri_v, obj_n, counts,
-                       lim.cells + 1);
-    // the scans run over sizes the host knows - the object count, and the CAPACITY of the per-cell arrays (entries past the
-    // grid's last cell are zero, so every prefix up to it is what a scan of the exact length would give)
+    hipLaunchKernelGGL(kf_head, dim3(1), dim3(1024), 0, st, boxes, tri_v, nb, nt, cell_size, tm, lim, meta, obj_off, counts, lim.cells + 1);
+    // the scan below runs over a size the host knows - the CAPACITY of the per-cell arrays (entries past the grid's last
+    // cell are zero, so every prefix up to it is what a scan of the exact length would give)
     size_t bytes = 0;
-    RT_HIP(c, rocprim::exclusive_scan(nullptr, bytes, obj_n, obj_off, 0u, (size_t)total + 1, rocprim::plus<uint32_t>(), st));
-    RT_HIP(c, c->b_scan_tmp.reserve(bytes + 256));
-    RT_HIP(c, rocprim::exclusive_scan(c->b_scan_tmp.p, bytes, obj_n, obj_off, 0u, (size_t)total + 1, rocprim::plus<uint32_t>(), st));
     const dim3 pair_grid((lim.pairs + 255) / 256);
     hipLaunchKernelGGL(kf_bin_count, pair_grid, dim3(256), 0, st, meta, lim, cell_size, nb, nt, tm, boxes, tri_v, (const uint32_t*)obj_off,
                        counts, slots, pair_cell, pair_id);

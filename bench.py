@@ -45,6 +45,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP gives a process a few hardware queues (four by default) and deals its streams out to them as they are first used;
+# a stream keeps its queue, and two busy streams on one queue run one after the other. This program keeps three streams
+# busy in its headline leg, and afterwards up to three contexts at once in the legs of the other configurations. When
+# every leg made streams of its own - torch hands out another of its 32 pooled streams each time - the contexts' streams
+# ended up on ONE queue (the animated model's two-context frame 0.19 -> 0.35 ms after as few as six headline frames on
+# three fresh streams: tools/hw_queues_probe.py). Every leg now takes its streams from one small set
+# (ray_tracer_amd.shared_stream), which cures it with four queues and with more. RT_BENCH_HW_QUEUES (development)
+# sets GPU_MAX_HW_QUEUES for this process; it must be in the environment before the HIP runtime starts.
+if os.environ.get("RT_BENCH_HW_QUEUES"):
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["RT_BENCH_HW_QUEUES"]
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -143,7 +154,7 @@ def streaming_leg(rt, dev, steps, warmup):
     cam = rt.Camera((0, 0, 75), math.pi, 0.0).to_uniform(0.0, float(h))
     outs = (torch.empty((w * h, 2), dtype=torch.int32, device=dev), torch.empty((w * h, 2), dtype=torch.int32, device=dev))
     ref, mov = count_frame(core, cam, w, h, outs)
-    stream = torch.cuda.Stream(device=dev)
+    stream = rt.shared_stream(dev, 0)
     core.set_stream(stream.cuda_stream)
     for _ in range(warmup):
         core.trace_primary(cam, w, h, shadow=True, out_primary=outs[0], out_shadow=outs[1])
@@ -158,7 +169,7 @@ def streaming_leg(rt, dev, steps, warmup):
     # the same frames three in flight (three streams, three pairs of output arrays), as the headline leg runs its own:
     # the host's clock around the frames between two device-wide waits
     flight = [outs] + [(torch.empty_like(outs[0]), torch.empty_like(outs[1])) for _ in range(2)]
-    streams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(2)]
+    streams = [stream] + [rt.shared_stream(dev, k) for k in (1, 2)]
 
     def frames(count):
         for k in range(count):
@@ -462,7 +473,7 @@ def main():
     cull_blocks, cull_kept = moved["pixel_blocks"], moved["pixel_blocks_traced"]
 
     if not multi:
-        streams = [torch.cuda.Stream(device=dev) for _ in range(FRAMES_IN_FLIGHT)]
+        streams = [rt.shared_stream(dev, k) for k in range(FRAMES_IN_FLIGHT)]  # the same few streams in every leg: see there
         bufs = [(torch.empty((WIDTH * HEIGHT, 2), dtype=torch.int32, device=dev),
                  torch.empty((WIDTH * HEIGHT, 2), dtype=torch.int32, device=dev)) for _ in range(FRAMES_IN_FLIGHT)]
         counter = [0]

@@ -7,4 +7,4 @@ from ._lib import (BOX_DTYPE, HIT_DTYPE, MATERIAL_DTYPE, RT_COMM_ID_BYTES, RT_ER
                    RT_ERR_STATE, RT_GRID_HIERARCHICAL, RT_GRID_TRIANGLES, RT_MISS, RT_NOALLOC_MAX_BOXES, RT_OWNER_SKY, TRIANGLE_DTYPE,
                    CameraUniform, GridMetadata, RayDebugInfo, RtParams, RtShard, RtStats)
 from .host import (DEFAULT_FOV, Camera, RayTracer, RtError, TraceCore, default_params, shard_pixels,  # noqa: F401
-                   triangles_from_xyz9)
+                   shared_stream, triangles_from_xyz9)

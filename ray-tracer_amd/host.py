@@ -520,6 +520,24 @@ class TraceCore:
         return out
 
 
+_SHARED_STREAMS = {}
+
+
+def shared_stream(device, k):
+    """The k-th of a small set of torch streams kept per device for the life of the process. HIP deals a process's
+    streams out to a few hardware queues (four by default) as they are first used, and a stream keeps its queue; two
+    busy streams on one queue run one after the other. A program that makes fresh streams for every phase - torch
+    hands out another of its 32 pooled streams each time - ends up with contexts whose streams share a queue. Frames in
+    flight, groups in flight and benchmark legs all take their streams from here: slot k is the same stream every time."""
+    import torch
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    pool = _SHARED_STREAMS.setdefault(key, [])
+    while len(pool) <= k:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[k]
+
+
 def triangles_from_xyz9(xyz9, material_id=0):
     """(n,9) float32 vertex rows -> TriangleData records (src/types.rs:211-233 with zero uvs)."""
     xyz9 = np.ascontiguousarray(xyz9, np.float32).reshape(-1, 9)

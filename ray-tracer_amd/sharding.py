@@ -36,7 +36,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import RT_OWNER_SKY, RtShard
-from .host import shard_pixels
+from .host import shard_pixels, shared_stream
 
 
 def n_tiles(width, height, tile_w, tile_h):
@@ -139,9 +139,9 @@ def _order_after_fill(stream, device):
 class _Slot:
     """Buffers and stream of one frame in flight."""
 
-    def __init__(self, sharder, device):
+    def __init__(self, sharder, device, k=0):
         s = sharder
-        self.stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
+        self.stream = shared_stream(device, k) if torch.device(device).type == "cuda" else None
         if s.mode == "rgba":
             # [record][r, g, b, a]; tiles this rank does not own stay zero
             self.local = torch.zeros((s.per_rank, 4), dtype=torch.uint8, device=device)
@@ -163,9 +163,9 @@ class _Slot:
 class _GroupSlot:
     """Buffers and stream of one group of frames in flight: [frame][record][r, g, b, a] per rank."""
 
-    def __init__(self, sharder, device):
+    def __init__(self, sharder, device, k=0):
         s = sharder
-        self.stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
+        self.stream = shared_stream(device, k) if torch.device(device).type == "cuda" else None
         self.local = torch.zeros((s.group, s.per_rank, s.wire_bytes), dtype=torch.uint8, device=device)
         self.packed = self.images = None
         self.views = {}
@@ -226,7 +226,7 @@ class FrameSharder:
         self.blocks = 2 if shadow else 1
         # Trace kernels, the gather and the assemble kernel of a frame share one in-order stream: the collective
         # only waits for work queued on torch's current stream, and makes that stream wait for its completion.
-        self.slots = [_Slot(self, device) for _ in range(max(1, frames_in_flight))]
+        self.slots = [_Slot(self, device, k) for k in range(max(1, frames_in_flight))]
         self.frame = 0
         self.sparse, self._tile_flags, self._plans = False, {}, {}
         self.last_wire_bytes = 0  # bytes one rank's block of the most recent group holds (what a rank sends)
@@ -272,7 +272,7 @@ class FrameSharder:
             raise ValueError("a group holds 1 to 64 frames (up to four rt_render_frames launches of 16)")
         self.group = group
         self.wire_bytes = 3 if rgb8 else 4
-        self.gslots = [_GroupSlot(self, self.device) for _ in range(max(1, groups_in_flight))]
+        self.gslots = [_GroupSlot(self, self.device, k) for k in range(max(1, groups_in_flight))]
 
     # ---- sky tiles stay at home
     def enable_sparse(self):

@@ -125,7 +125,7 @@ def massive(rt, dev, width, height, sizes, dup_modes, repeats=None, name="massiv
     flight = [(torch.empty((width * height, 2), dtype=torch.int32, device=dev), torch.empty((width * height, 2), dtype=torch.int32, device=dev))
               for _ in range(3)]
     outs = flight[0]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    streams = [rt.shared_stream(dev, k) for k in range(3)]
     legs = []
     for n in sizes:
         tris = wl.generate_test_triangles(n)

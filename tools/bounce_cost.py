@@ -19,8 +19,9 @@ PLAIN = os.environ.get("RT_PLAIN_BOUNCES") == "1"  # rt_render_opts.plain_bounce
 core = rt.TraceCore(0)
 tris, mats, textures = bundled_model(rt, "car", np.load(os.path.join(ROOT, "tests/golden/car_tris.npy")))
 cam = rt.Camera.for_scene("gltf").to_uniform(0.0, float(H))
-streams = [torch.cuda.Stream() for _ in range(2)]
-outs = [torch.empty((W * H, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+NF = int(os.environ.get("RT_INFLIGHT", "2"))  # frames in flight
+streams = [rt.shared_stream("cuda:0", k) for k in range(NF)]
+outs = [torch.empty((W * H, 4), dtype=torch.uint8, device="cuda") for _ in range(NF)]
 if os.environ.get("RT_ALPHA_OPAQUE") == "1":  # no hit is decided by a texture's alpha: the picture kernel that shares bounce rays' lists may run
     mats = mats.copy()
     mats["alpha_mode"] = 0
@@ -37,8 +38,8 @@ for bounces in (1, 2, 3, 4, 8):
 
     def frames(n):
         for k in range(n):
-            core.set_stream(streams[k % 2].cuda_stream)
-            core.render(cam, W, H, max_bounces=bounces, shadows=False, out=outs[k % 2], plain_bounces=PLAIN)
+            core.set_stream(streams[k % NF].cuda_stream)
+            core.render(cam, W, H, max_bounces=bounces, shadows=False, out=outs[k % NF], plain_bounces=PLAIN)
         core.sync()
     frames(10)
     t0 = time.perf_counter()

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Development tool: the headline figure and the config legs of a saved bench.py line, one per row.
+Usage: python3 tools/show_configs.py <file holding bench.py's JSON line>"""
 import sys,json
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(d["value"], d["ms_per_step"], d["configs_wall_s"])

@@ -12,7 +12,7 @@ def _eq_hits(a, b):
     return np.array_equal(a["id"], b["id"]) and np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32))
 
 
-def test_grid_statistics_match_survey_numbers(ob, car_xyz9, phoenix_xyz9):
+def test_grid_statistics_of_the_bundled_models(ob, car_xyz9, phoenix_xyz9):
     car = ob.Grid(None, ob.triangles_from_xyz9(car_xyz9))
     assert car.meta.fine_dims == (67, 12, 84) and car.n_cells == 67536 and car.n_refs == 34430
     occ = np.diff(car.cell_start.astype(np.int64))

@@ -323,6 +323,17 @@ def preheat(step, sync, steps_per_pass, dist, device):
     return passes
 
 
+def secondary(name, leg):
+    """A leg beside the headline measurement: whatever goes wrong in it is reported in its place (and on stderr), and the
+    line with the headline figure is still printed."""
+    try:
+        return leg()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        return {"error": f"{name}: {type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -682,7 +693,8 @@ def main():
                                             "config.cell_refs); the fetched figure counts what they walk.")
             if os.environ.get("RT_BENCH_LEG", "both") != "headline" and WORKLOAD == "car1080":
                 core.close()
-                out["roofline_streaming"] = streaming_leg(rt, dev, int(os.environ.get("RT_BENCH_STREAM_STEPS", "20")), 3)
+                out["roofline_streaming"] = secondary("roofline_streaming", lambda: streaming_leg(
+                    rt, dev, int(os.environ.get("RT_BENCH_STREAM_STEPS", "20")), 3))
             # the other BASELINE configurations on this GPU, one bounded leg each (tools/config_legs.py); RT_BENCH_CONFIGS=0
             # leaves them out (profiling runs of the headline kernel)
             if WORKLOAD == "car1080" and os.environ.get("RT_BENCH_CONFIGS", "1") != "0" and os.environ.get("RT_BENCH_LEG", "both") == "both":
@@ -690,9 +702,13 @@ def main():
                     core.close()
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import config_legs
-                out["configs"], out["configs_wall_s"] = config_legs.all_legs(rt, dev)
+                legs = secondary("configs", lambda: config_legs.all_legs(rt, dev))
+                if isinstance(legs, tuple):
+                    out["configs"], out["configs_wall_s"] = legs
+                else:
+                    out["configs"] = legs
             if not args.no_cpu_baseline and xyz9 is not None:
-                out["cpu_baseline"] = cpu_baseline(xyz9, WIDTH, HEIGHT)
+                out["cpu_baseline"] = secondary("cpu_baseline", lambda: cpu_baseline(xyz9, WIDTH, HEIGHT))
         emit(json.dumps(out))
     if core._h:
         core.close()

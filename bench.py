@@ -542,7 +542,8 @@ def main():
 
     base_ms = None
     if multi and rank == 0:  # the single-GPU figure of the same route, measured while the other ranks wait
-        base_ms = same_route_single_gpu(core, sharding, cam, dev, max(64, args.steps))
+        base_ms = secondary("scaling_base", lambda: same_route_single_gpu(core, sharding, cam, dev, max(64, args.steps)))
+        base_ms = None if isinstance(base_ms, dict) else base_ms  # an extra beside the measurement: reported on stderr if it fails
     # Untimed, before the W warm-up steps: the same steps for PREHEAT_MS of wall time, so that the timed region runs at
     # the clocks a renderer sees in steady state however few steps the caller asks for (the first tens of milliseconds
     # after an idle period run ~6 % slower: clock ramp).
@@ -591,7 +592,8 @@ def main():
             lat.append(e0.elapsed_time(e1) * 1e3)
         single_us = float(np.median(lat[5:]))
     if not multi:
-        base_ms = same_route_single_gpu(core, sharding, cam, dev, max(64, args.steps))
+        base_ms = secondary("scaling_base", lambda: same_route_single_gpu(core, sharding, cam, dev, max(64, args.steps)))
+        base_ms = None if isinstance(base_ms, dict) else base_ms  # an extra beside the measurement: reported on stderr if it fails
     hbm_copy = None
     if not multi:  # what this GPU's HBM delivers on the library's plain copy kernel (2 GiB read + 2 GiB written per pass)
         a = torch.zeros(1 << 29, dtype=torch.float32, device=dev)

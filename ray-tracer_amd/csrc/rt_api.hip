@@ -930,6 +930,17 @@ int launch_primary(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const Dev
     return RT_OK;
 }
 
+// Ray lists of up to 32 768 rays (a quarter of the chip's wave slots at four lanes each) are traced four lanes to a ray:
+// with so few waves the four walks of the grid cost nothing, and where lists are long the chain is what the call waits
+// for (bundled static model, 1 000 / 20 000 rays: 99 -> 50 us / 132 -> 63 us; the generator's scene on its tuned grid,
+// short lists: 87 -> 84 / 99 -> 100). Beyond that it depends on the scene (100 000 rays: 134 -> 70 us on the model,
+// 96 -> 119 on the generator's scene), so a lane to a ray stays. RT_RAY_LANES=1 / 4 (development, tests): that form
+// whatever the count.
+static bool rays_take_four_lanes(uint32_t n) {
+    const char* lanes = getenv("RT_RAY_LANES");
+    return n != 0 && (lanes ? atoi(lanes) == 4 : n <= 32768u);
+}
+
 template <bool WGSL, bool ANY>
 void launch_rays(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const float* o, const float* d, uint32_t n,
                  uint2* out) {
@@ -954,6 +965,9 @@ void launch_rays(rt_ctx* c, int stats, dim3 grid, const DevScene& s, const float
         hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, true>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
     else if (c->params.repack_candidates && n != 0)
         hipLaunchKernelGGL((k_trace_rays_repack<WGSL, ANY>), grid, dim3(256), 0, c->stream, s, o, d, n, out);
+    else if (rays_take_four_lanes(n))  // a list that leaves the chip idle behind its rays' dependent chains
+        hipLaunchKernelGGL((k_trace_rays_quad<WGSL, ANY>), dim3((uint32_t)(((size_t)n * 4 + 255) / 256)), dim3(256), 0, c->stream, s, o, d,
+                           n, out);
     else
         hipLaunchKernelGGL((k_trace_rays<WGSL, ANY, 0, false>), grid, dim3(256), 0, c->stream, s, o, d, n, out, st);
 }

@@ -1611,6 +1611,23 @@ __global__ __launch_bounds__(256) void k_trace_rays(DevScene s, const float* __r
     if (STATS) flush_stats(stats, n_rays, n_hit, 0, 0, ctr);
 }
 
+// k_trace_rays for lists too short to fill the chip (triangle-only scenes, no counters): four lanes to a ray. Every
+// lane walks the grid; a cell's list is dealt to the ray's four lanes and the four results meet under the key
+// (t, list position), which is what a scan in order with a strict '<' yields (trace_ray<X = TRACE_QUAD>, the form the
+// plan of expensive blocks uses) - same records bit for bit, a ray's chain of candidate tests a quarter as long.
+template <bool WGSL, bool ANY>
+__global__ __launch_bounds__(256) void k_trace_rays_quad(DevScene s, const float* __restrict__ origins, const float* __restrict__ dirs,
+                                                         uint32_t n, uint2* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = (uint32_t)(t >> 2);
+    if (i >= n) return;  // a ray's four lanes leave together
+    Counters ctr{};
+    HitRec h;
+    const RayDir rd = make_ray_dir<WGSL>(ld3(dirs + 3 * (size_t)i), s.cell_size, s.px, s.pxy);
+    const bool hit = trace_ray<WGSL, ANY, 0, false, false, false, TRACE_QUAD>(s, ld3(origins + 3 * (size_t)i), rd, h, ctr, 4u);
+    if ((threadIdx.x & 3u) == 0) out[i] = hit ? make_uint2(h.id, __float_as_uint(h.t)) : make_uint2(MISS, 0u);
+}
+
 // k_trace_rays with trace_ray_repack as the traversal (rt_params.repack_candidates): a caller's ray list is rarely
 // ordered so that neighbouring rays share their cells. Lanes past the end of the list take part without a ray.
 template <bool WGSL, bool ANY>

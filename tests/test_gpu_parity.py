@@ -122,6 +122,36 @@ def test_aabb_pairs_ragged_sizes_host_and_device(rt, ob, n_rays, n_prims):
     core.close()
 
 
+@pytest.mark.parametrize("any_hit", [0, 1])
+def test_ray_lists_one_lane_and_four_lanes_to_a_ray(rt, ob, car_xyz9, any_hit):
+    """rt_trace_rays walks short lists four lanes to a ray (a cell's list dealt to the four, results merged under (t, list
+    position)) and long ones a lane to a ray: the same records either way, and the oracle's, closest hit and any hit."""
+    import os
+    tris = ob.triangles_from_xyz9(car_xyz9)
+    cam = ob.camera_to_uniform((200, 200, 300), 3.35, -0.28, 0.0, 135.0)
+    o, d = ob.primary_rays(cam, 240, 135)
+    rng = np.random.default_rng(5)
+    o2 = rng.uniform(-300, 300, (5000, 3)).astype(np.float32)  # rays in no order, many from inside the grid
+    d2 = rng.normal(size=(5000, 3)).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True).astype(np.float32)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    scene = ob.Scene(None, tris)
+    want, _ = ob.trace_rays(scene, o, d, any_hit=bool(any_hit))
+    core = rt.TraceCore(0)
+    core.set_scene(None, tris)
+    core.build_grid()
+    try:
+        for lanes in ("1", "4"):
+            os.environ["RT_RAY_LANES"] = lanes
+            got = core.trace_rays(o, d, any_hit=bool(any_hit))
+            assert_hits_equal(got, want, f"{lanes} lane(s) to a ray")
+            for n in (1, 3, 63, 65):  # lists that end inside a wave, inside a ray's four lanes' wave
+                assert_hits_equal(core.trace_rays(o[:n], d[:n], any_hit=bool(any_hit)), want[:n], f"{lanes} lanes, {n} rays")
+    finally:
+        os.environ.pop("RT_RAY_LANES", None)
+    core.close()
+
+
 @pytest.mark.parametrize("wgsl", [0, 1])
 def test_tri_pairs(rt, ob, car_xyz9, wgsl):
     core = rt.TraceCore(0, rt.default_params(wgsl_compat=wgsl))

@@ -169,7 +169,10 @@ def animated(rt, dev, frames=int(os.environ.get("RT_ANIM_FRAMES", "200"))):
     legs = []
     # four contexts are slower again (0.23 ms: a process has four hardware queues). threads: one host thread per context
     # (a rebuild ends with a 56-byte read-back the host waits for; with a thread each, the other contexts' launches go on)
-    for n_ctx, heavy, threads in ((1, 0, False), (1, 64, False), (2, 0, False), (2, 64, False), (3, 0, False), (3, 64, False), (3, 0, True), (3, 64, True)):
+    legs_wanted = ((1, 0, False), (1, 64, False), (2, 0, False), (2, 64, False), (3, 0, False), (3, 64, False), (3, 0, True), (3, 64, True))
+    if os.environ.get("RT_ANIM_LEGS"):  # development: "contexts,threshold,threads;..." instead
+        legs_wanted = tuple((int(a), int(b), bool(int(c))) for a, b, c in (leg.split(",") for leg in os.environ["RT_ANIM_LEGS"].split(";")))
+    for n_ctx, heavy, threads in legs_wanted:
         only = os.environ.get("RT_ANIM_ONLY")  # development: one leg, e.g. "1,64,0" (contexts, threshold, threads)
         if only and tuple(int(v) for v in only.split(",")) != (n_ctx, heavy, int(threads)):
             continue
